@@ -1,0 +1,454 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (the parity oracle) of LDT's sampling hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module.  The product (`ldt_amd/`) never does.
+
+What it is: a from-scratch, *functional*, token-major PyTorch-fp32 restatement of
+the reference algorithm.  Every function takes a plain
+`state_dict` (reference parameter names/shapes: Conv1d weights are (out,in,1))
+and cites the reference file:line it follows (paths relative to /root/reference).
+
+Pinning: `tests/test_oracle_golden.py` checks every function here against golden
+vectors captured from the *imported reference itself* by `oracle/gen_golden.py`
+(fixtures under tests/golden/).  Exception — **FPS parity unpinned**: the
+reference calls the third-party `pointnet2_ops` CUDA kernel (not vendored, not in
+this image; call site model/Compressor/layers.py:106); we restate the algorithm of
+its vendored twin model/functional/src/sampling/sampling.cu:86-167 instead.
+
+Layout convention: the reference is channels-first (B,C,T) with 1x1 Conv1d; here
+everything is token-major X[B,T,C] and a Conv1d weight W(out,in,1) is X @ W[:,:,0].T + b.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------- helpers
+
+
+def _w(sd, name):
+    """Weight as a 2-D (out,in) matrix whether it is Linear (out,in) or Conv1d (out,in,1)."""
+    w = sd[name]
+    return w[:, :, 0] if w.dim() == 3 else w
+
+
+def linear(sd, prefix, x):
+    """1x1 Conv1d / Linear: x[..., in] -> [..., out]."""
+    return F.linear(x, _w(sd, prefix + ".weight"), sd.get(prefix + ".bias"))
+
+
+def layer_norm(x, weight=None, bias=None):
+    """tools/utils.py:127-133: nn.LayerNorm(C, eps=1e-6) over channels."""
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, 1e-6)
+
+
+def modulate(x, shift, scale):
+    """model/layers.py:136-137 (shift/scale broadcast over tokens)."""
+    return x * (1 + scale) + shift
+
+
+# ----------------------------------------------------------------------------- time embedding
+
+
+def sinusoid(t, dim):
+    """model/layers.py:20-36 (calc_t_emb): continuous t, [sin | cos], fp32 frequency product."""
+    half = dim // 2
+    s = np.log(10000) / (half - 1)           # python/fp64 scalar, :29
+    f = torch.exp(torch.arange(half) * -s)   # int64 * python float -> fp32 product, :30
+    e = t.unsqueeze(1) * f                   # :33
+    return torch.cat((torch.sin(e), torch.cos(e)), 1)
+
+
+def time_embedding(sd, prefix, t, t_emb_dim):
+    """model/layers.py:14-41: Linear -> SiLU -> Linear on the sinusoid."""
+    e = sinusoid(t, t_emb_dim)
+    h = F.silu(linear(sd, prefix + ".mlp.0", e))
+    return linear(sd, prefix + ".mlp.2", h)
+
+
+# ----------------------------------------------------------------------------- attention / block
+
+
+def attention(sd, prefix, xq, xkv, num_heads):
+    """model/layers.py:183-200 compute_attention.
+
+    xq [B,N,C] (query source), xkv [B,M,Ckv].  K = first C output channels of
+    fc_kv, V = last C (:189).  Head merge is a RAW reinterpret of the contiguous
+    (B,H,N,Dh) result as (B,N,C) (:197, quirk Q1)."""
+    B, N, _ = xq.shape
+    q = linear(sd, prefix + ".fc_q", xq)
+    kv = linear(sd, prefix + ".fc_kv", xkv)
+    C = q.shape[-1]
+    M = kv.shape[1]
+    dh = C // num_heads
+    k, v = kv[..., :C], kv[..., C:]
+    qh = q.reshape(B, N, num_heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(B, M, num_heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(B, M, num_heads, dh).permute(0, 2, 1, 3)
+    w = (qh @ kh.transpose(-2, -1)) * (dh ** -0.5)
+    w = w.softmax(dim=-1)
+    o = (w @ vh).contiguous()                  # (B,H,N,Dh) contiguous
+    o = o.reshape(B, N, C)                     # raw reinterpret, no head permute-back
+    return linear(sd, prefix + ".fc_o", o)
+
+
+def mlp(sd, prefix, x):
+    """model/layers.py:110-133 with n_hidden=1: Conv -> GELU(erf) -> Conv."""
+    return linear(sd, prefix + ".out", F.gelu(linear(sd, prefix + ".fc.0.0", x)))
+
+
+def residual_block(sd, prefix, x, y, c, num_heads):
+    """model/layers.py:202-229 (dim_in == dim_out, shortcut = Identity).
+
+    c is not None  -> AdaLN branch (:212-219), LayerNorm without affine.
+       y is None   -> K/V from the modulated-normalised x (Score, :184-185)
+       y given     -> K/V from RAW y (Compressor Encoder passes y=x, quirk Q2)
+    c is None      -> no-condition branch (:224-226), LayerNorm WITH affine, act=Identity
+                      (decoder_act: ~ in the shipped config)."""
+    if c is not None:
+        m = linear(sd, prefix + ".adaLN.1", F.silu(c))[:, None, :]      # [B,1,6C]
+        sh1, sc1, g1, sh2, sc2, g2 = m.chunk(6, dim=-1)
+        h = modulate(layer_norm(x), sh1, sc1)
+        x = x + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
+        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
+    else:
+        h = layer_norm(x, sd[prefix + ".norm1.norm.weight"], sd[prefix + ".norm1.norm.bias"])
+        x = x + attention(sd, prefix, h, h if y is None else y, num_heads)
+        h = layer_norm(x, sd[prefix + ".norm2.norm.weight"], sd[prefix + ".norm2.norm.bias"])
+        x = x + mlp(sd, prefix + ".mlp", h)
+    return x
+
+
+def final_layer(sd, prefix, x, c):
+    """model/layers.py:232-248: chunk order is (shift, scale)."""
+    m = linear(sd, prefix + ".adaLN.1", F.silu(c))[:, None, :]
+    sh, sc = m.chunk(2, dim=-1)
+    return linear(sd, prefix + ".ln", modulate(layer_norm(x), sh, sc))
+
+
+# ----------------------------------------------------------------------------- Score
+
+
+def score_forward(sd, cfg, x, t, label_emb=None, condition=None, trace=None):
+    """model/scorenet/score.py:117-151 (unet: False path).
+
+    x [B,T,z], t [B].  condition = (pts_cond [B,S,hidden] token-major or None, img_cond [B,t_dim] or 0.)
+    label_emb: already-embedded label [B,t_dim] (LabelEmbedding, layers.py:44-52) — label wins over
+    the image condition (operator precedence at score.py:135)."""
+    pts_cond, img_cond = (None, 0.) if condition is None else condition
+    t_emb = time_embedding(sd, "TimeEmbedding", t, cfg.t_dim // 4)
+    c = t_emb + label_emb if label_emb is not None else t_emb + img_cond
+    h = linear(sd, "ln_in", x)
+    if trace is not None:
+        trace.append(("c", c.clone()))
+        trace.append(("ln_in", h.clone()))
+    for i in range(cfg.num_blocks):
+        y = pts_cond if (i % 2 == 0) else None
+        h = residual_block(sd, "Transformer.%d" % i, h, y, c, cfg.num_heads)
+        if trace is not None:
+            trace.append(("block%d" % i, h.clone()))
+    return final_layer(sd, "ln_out", h, c)
+
+
+# ----------------------------------------------------------------------------- VPSDE + samplers
+
+
+class VPSDE:
+    """diffusion/diffusion_continuous.py:626-678 (DiffusionVPSDE), discrete sample mode."""
+
+    def __init__(self, sde_cfg):
+        self.beta_start = sde_cfg.beta_start
+        self.beta_end = sde_cfg.beta_end
+        self.sigma2_0 = sde_cfg.sigma2_0
+        self.N = sde_cfg.sample_N
+        # :649-653 — fp64 linspace cast to fp32
+        self.betas = torch.from_numpy(
+            np.linspace(self.beta_start / self.N, self.beta_end / self.N, self.N, dtype=np.float64)).to(torch.float32)
+        self.alpha = 1.0 - self.betas
+        self.alphas_cump = self.alpha.cumprod(dim=0)
+
+    def g2(self, t):  # :658-659
+        return self.beta_start + (self.beta_end - self.beta_start) * t
+
+    def f(self, t):  # :655-656
+        return -0.5 * self.g2(t)
+
+    def var(self, t):  # :664-666 (same op order => same fp32 rounding)
+        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
+            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+
+    def std(self, t):  # :668-669
+        return torch.sqrt(self.var(t))
+
+    def e2int_f(self, t):  # :671-672
+        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
+
+
+def score_fn_from_model(sde, model_fn):
+    """trainer/Latent_SDE_Trainer.py:57-61: params -> (score, params)."""
+    def fn(t, x):
+        params = model_fn(x, t)
+        var = sde.var(t)[:, None, None]
+        return -params / torch.sqrt(var), params
+    return fn
+
+
+def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_eps=1e-6,
+                    denoise=True, probability_flow=False, record=None):
+    """diffusion/diffusion_continuous.py:133-258,318-338 (pc_sampling, corrector=None).
+
+    x0 [B,T,z] is the initial N(0,1) draw (:237), noises[i] the step-i draw of
+    randn_like(x) (:160 etc.; the last one is drawn but unused when denoise, quirk Q8).
+    record: optional list that receives (x_in, params, x_mean, x_out) per step."""
+    T = 1.0
+    B = x0.shape[0]
+    x = x0
+    timesteps = torch.linspace(T, time_eps, N)                      # :238
+    x_mean = x
+    for i in range(N):
+        t = torch.ones((B,)) * timesteps[i]                         # :243-244
+        z = noises[i]
+        if predictor == "ancestral":                                # :152-162
+            idx = (t * (N - 1) / T).long()
+            beta = sde.betas[idx]
+            score, params = score_fn(t, x)
+            x_mean = (x + beta[:, None, None] * score) / torch.sqrt(1. - beta)[:, None, None]
+            x_new = x_mean + torch.sqrt(beta)[:, None, None] * z
+        elif predictor == "reversediffusion":                       # :141-150
+            dt = torch.tensor((1 - time_eps) / N)
+            f, g2 = sde.f(t)[:, None, None] * x, sde.g2(t)[:, None, None]
+            score, params = score_fn(t, x)
+            dx = (f - g2 * score * (0.5 if probability_flow else 1.)) * dt
+            g = torch.zeros_like(g2) if probability_flow else torch.sqrt(g2)
+            x_mean = x - dx
+            x_new = x_mean + g * z * torch.sqrt(dt)
+        elif predictor == "eulermaruyama":                          # :182-191
+            dt = -1. / N
+            f, g2 = sde.f(t)[:, None, None] * x, sde.g2(t)[:, None, None]
+            score, params = score_fn(t, x)
+            f = f - g2 * score * (0.5 if probability_flow else 1.)
+            x_mean = x + f * dt
+            g2 = torch.zeros(1) if probability_flow else g2
+            x_new = x_mean + torch.sqrt(g2) * np.sqrt(-dt) * z
+        elif predictor == "ddim":                                   # :164-180
+            idx = (t * (N - 1) / T).long()
+            at = sde.alphas_cump[idx][:, None, None]
+            if idx[0] - 1 < 0:
+                at_next = torch.ones_like(at)
+            else:
+                at_next = sde.alphas_cump[idx - 1][:, None, None]
+            _, params = score_fn(t, x)
+            x_mean = at_next.sqrt() * (x - (1 - at).sqrt() * params) / at.sqrt() + (1 - at_next).sqrt() * params
+            x_new = x_mean + 0 * z
+        else:
+            raise NotImplementedError("preditor not Implemented")   # :328
+        if record is not None:
+            record.append((x, params, x_mean, x_new))
+        x = x_new
+    return x_mean if denoise else x
+
+
+# ----------------------------------------------------------------------------- Compressor: decode
+
+
+def initial_set(sd, B, num_points=None, keep_mask=None):
+    """model/Compressor/layers.py:26-37 with max_outputs set: learned prior rows, token-major [B,N,D].
+    keep_mask [B,max_outputs] bool selects rows (index order) when num_points < max_outputs;
+    with num_points == max_outputs every row is kept in order (quirk Q9)."""
+    prior = sd["init_set.prior"]
+    if keep_mask is None:
+        return prior[None].expand(B, -1, -1)
+    return torch.stack([prior[keep_mask[b]] for b in range(B)], 0)
+
+
+def decoder_block(sd, prefix, o, eps_j, num_heads):
+    """model/Compressor/Network.py:80-83: o <- att1(o, ln(eps_j)) (no-condition block, K/V raw)."""
+    z = linear(sd, prefix + ".ln", eps_j)
+    return residual_block(sd, prefix + ".att1", o, z, None, num_heads)
+
+
+def compressor_decode(sd, cfg, given_eps, keep_mask=None):
+    """model/Compressor/Network.py:251-268 Compressor.sample: given_eps [B,T,n_layers*z_dim] -> [B,N,3]."""
+    B = given_eps.shape[0]
+    o = initial_set(sd, B, keep_mask=keep_mask)
+    for j in range(cfg.n_layers):
+        blk = "decoder.%d" % (cfg.n_layers - 1 - j)                 # reversed(self.decoder), :263
+        e_j = given_eps[:, :, cfg.z_dim * j: cfg.z_dim * (j + 1)]  # split along channels, :261-262
+        o = decoder_block(sd, blk, o, e_j, cfg.num_heads)
+    return linear(sd, "output", o)                                  # postprocess = identity for xyz, :271-275
+
+
+# ----------------------------------------------------------------------------- Compressor: encode
+
+
+def fps(xyz, m):
+    """Farthest point sampling, restating model/functional/src/sampling/sampling.cu:86-167
+    (the vendored twin of pointnet2_ops' kernel; **parity unpinned**, see module header).
+    Start index 0; distances init 1e38 (sampling.cpp:53-54); running min; argmax; ties go to the
+    smaller (k % 512, k // 512) as the 512-thread strided scan + pairwise tree does (:141-158).
+    Squared distance is (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction."""
+    xyz = np.ascontiguousarray(xyz.detach().cpu().numpy(), dtype=np.float32)
+    b, n, _ = xyz.shape
+    out = np.zeros((b, m), dtype=np.int64)
+    k = np.arange(n)
+    tie_rank = (k % 512) * (n // 512 + 1) + k // 512
+    for bi in range(b):
+        p = xyz[bi]
+        dist = np.full((n,), np.float32(1e38), dtype=np.float32)
+        old = 0
+        for j in range(1, m):
+            dx = p[:, 0] - p[old, 0]
+            dy = p[:, 1] - p[old, 1]
+            dz = p[:, 2] - p[old, 2]
+            d = (dx * dx + dy * dy) + dz * dz
+            dist = np.minimum(d, dist)
+            best = dist.max()
+            cand = np.nonzero(dist == best)[0]
+            old = int(cand[np.argmin(tie_rank[cand])])
+            out[bi, j] = old
+    return torch.from_numpy(out)
+
+
+def square_distance(src, dst):
+    """model/Compressor/layers.py:65-84: -2ab + |a|^2 + |b|^2 (expanded form, in this op order)."""
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).view(B, N, 1)
+    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
+    return dist
+
+
+def knn(k, xyz, centers):
+    """model/Compressor/layers.py:87-98: k smallest squared distances, unordered."""
+    d = square_distance(centers, xyz)
+    return torch.topk(d, k, dim=-1, largest=False, sorted=False)[1]
+
+
+def gather(points, idx):
+    """model/Compressor/layers.py:46-62 index_points: points [B,N,C], idx [B,...] -> [B,...,C]."""
+    B = points.shape[0]
+    flat = idx.reshape(B, -1)
+    out = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1]))
+    return out.reshape(*idx.shape, points.shape[-1])
+
+
+def batch_norm_eval(sd, prefix, x):
+    """nn.BatchNorm1d in eval mode on channel-last x (eps=1e-5)."""
+    return F.batch_norm(x.reshape(-1, x.shape[-1]), sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, 1e-5).reshape(x.shape)
+
+
+def local_grouper(sd, prefix, xyz, feat, groups, k, fps_idx=None, knn_idx=None):
+    """model/Compressor/layers.py:288-319 (normalize='anchor', use_xyz=True).
+    xyz [B,N,3], feat [B,N,D] -> centres [B,S,3], tokens [B,S,D]; also returns the index sets."""
+    B, N, _ = xyz.shape
+    if fps_idx is None:
+        fps_idx = fps(xyz, groups)                                   # cluster :106
+    new_xyz = gather(xyz, fps_idx)                                  # :107
+    if knn_idx is None:
+        knn_idx = knn(k, xyz, new_xyz)                              # :111
+    new_feat = gather(feat, fps_idx)                                # :299
+    g = torch.cat([gather(feat, knn_idx), gather(xyz, knn_idx)], dim=-1)     # :301-304  [B,S,k,D+3]
+    mean = torch.cat([new_feat, new_xyz], dim=-1).unsqueeze(-2)     # :308-310 anchor
+    std = torch.std((g - mean).reshape(B, -1), dim=-1, keepdim=True)[..., None, None]  # :311-312 unbiased
+    g = (g - mean) / (std + 1e-5)                                   # :313
+    g = sd[prefix + ".affine_alpha"] * g + sd[prefix + ".affine_beta"]       # :314
+    u = torch.cat([g, new_feat[:, :, None, :].expand(-1, -1, k, -1)], dim=-1)  # :315  [B,S,k,2D+3]
+    # PreExtraction :178-187
+    e = prefix + ".extraction"
+    h = F.relu(batch_norm_eval(sd, e + ".transfer.net.1", linear(sd, e + ".transfer.net.0", u)))
+    r = F.relu(batch_norm_eval(sd, e + ".operation.0.net1.1", linear(sd, e + ".operation.0.net1.0", h)))
+    r = linear(sd, e + ".operation.0.net2.0", r)
+    h = F.relu(r + h)
+    tokens = h.max(dim=2)[0]                                        # adaptive_max_pool1d over k
+    return new_xyz, tokens, fps_idx, knn_idx
+
+
+def mini_pointnet(sd, prefix, centers):
+    """model/Compressor/Network.py:86-101: centres [B,S,3] -> [B,p_dim]."""
+    h = F.relu(batch_norm_eval(sd, prefix + ".bn1", linear(sd, prefix + ".conv1", centers)))
+    h = F.relu(batch_norm_eval(sd, prefix + ".bn2", linear(sd, prefix + ".conv2", h)))
+    return linear(sd, prefix + ".fc", h.max(dim=1)[0])
+
+
+def act_norm(sd, prefix, x):
+    """model/layers.py:103-107 (eval): per-token/channel shift & log_scale of shape (1,T,C)."""
+    return (x - sd[prefix + ".shift"]) * torch.exp(-sd[prefix + ".log_scale"])
+
+
+def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep_mask=None):
+    """model/Compressor/Network.py:188-249 Compressor.forward (norm_input False, pre_group False,
+    pos_embedding 'center', ActNorm True, class_condition False).
+
+    pts [B,N,3]; post_noise: list of n_layers tensors [B,T,z_dim] token-major — the N(0,1) draws
+    of `sample(mu, logvar)` (:26-29) in consumption order.  Returns dict with 'all_eps' [B,T,n*z],
+    'set' [B,N,3], plus intermediates for parity tests."""
+    B, N, _ = pts.shape
+    T = cfg.z_scales
+    feat = linear(sd, "input", pts)                                             # :192
+    centers, x, fps_idx, knn_idx = local_grouper(sd, "group", pts, feat, T, N // T * 2, fps_idx, knn_idx)  # :195
+    pos = mini_pointnet(sd, "pos_embedding", centers)                           # :196
+    x = act_norm(sd, "conv_in", x)                                              # :200-201
+    enc_out = []
+    for i in range(cfg.n_layers):                                               # :203-205
+        for j in range(cfg.encoder_layers):
+            x = residual_block(sd, "encoder.%d.atts.%d" % (i, j), x, x, pos, cfg.num_heads)   # y = raw x (Q2)
+        enc_out.append(final_layer(sd, "encoder.%d.conv_out" % i, x, pos))
+    o = initial_set(sd, B, keep_mask=keep_mask)                                 # :215
+    all_eps, mus, logvars = [], [], []
+    for j in range(cfg.n_layers):                                               # :217-225
+        blk = "decoder.%d" % (cfg.n_layers - 1 - j)
+        xj = enc_out[-j - 1]
+        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, None, cfg.num_heads)   # :61-74
+        post = linear(sd, blk + ".prior.1", F.silu(p))                          # :56,:72
+        mu = post[..., :cfg.z_dim]
+        logvar = post[..., cfg.z_dim:].clamp(cfg.min_sigma, 10.)                # :76
+        eps = mu + torch.exp(logvar / 2.) * post_noise[j]                       # :26-29
+        o = decoder_block(sd, blk, o, eps, cfg.num_heads)                       # :225
+        all_eps.append(eps); mus.append(mu); logvars.append(logvar)
+    out = linear(sd, "output", o)                                               # :231
+    return {"set": out, "all_eps": torch.cat(all_eps, dim=-1), "mu": mus, "logvar": logvars,
+            "fps_idx": fps_idx, "knn_idx": knn_idx, "centers": centers, "enc_out": enc_out, "max": x.max()}
+
+
+# ----------------------------------------------------------------------------- Chamfer, Trainer.sample
+
+
+def dist_chamfer(a, b):
+    """evaluation/evaluation_metrics.py:23-33 distChamfer: squared-L2 NN both ways via bmm."""
+    xx = torch.bmm(a, a.transpose(2, 1))
+    yy = torch.bmm(b, b.transpose(2, 1))
+    zz = torch.bmm(a, b.transpose(2, 1))
+    rx = torch.diagonal(xx, dim1=1, dim2=2).unsqueeze(1).expand_as(xx)
+    ry = torch.diagonal(yy, dim1=1, dim2=2).unsqueeze(1).expand_as(yy)
+    P = rx.transpose(2, 1) + ry - 2 * zz
+    return P.min(1)[0], P.min(2)[0]
+
+
+def chamfer_cd(a, b):
+    """evaluation/evaluation_metrics.py:88: CD = dl.mean(1) + dr.mean(1)."""
+    dl, dr = dist_chamfer(a, b)
+    return dl.mean(dim=1) + dr.mean(dim=1)
+
+
+def trainer_sample(score_sd, comp_sd, cfg, x0, noises, record=None):
+    """trainer/Latent_SDE_Trainer.py:143-165 Trainer.sample (discrete mode, unconditional):
+    returns (points [B,N,3], eps [B,T,z])."""
+    sde = VPSDE(cfg.sde)
+    fn = score_fn_from_model(sde, lambda x, t: score_forward(score_sd, cfg.score, x, t))
+    eps = sample_discrete(sde, fn, x0, noises, cfg.sde.sample_N, predictor=cfg.sde.predictor,
+                          time_eps=cfg.sde.sample_time_eps, denoise=cfg.sde.denoise,
+                          probability_flow=cfg.sde.probability_flow, record=record)
+    pts = compressor_decode(comp_sd, cfg.compressor, eps)
+    return pts, eps
+
+
+def draw_noises(seed, B, T, z, N):
+    """The reference's draw order on the CPU generator: x0 (:237) then one randn per step (:160)."""
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn((B, T, z), generator=g)
+    noises = [torch.randn((B, T, z), generator=g) for _ in range(N)]
+    return x0, noises

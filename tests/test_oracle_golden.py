@@ -1,0 +1,177 @@
+"""CPU: pins the oracle (oracle/ldt_oracle.py) against golden vectors captured from the
+imported upstream reference (oracle/gen_golden.py).  fp32 vs fp32 on the same CPU => the bar is
+round-off (rel-MSE <= 1e-10; tables bit-exact)."""
+import numpy as np
+import torch
+
+from conftest import load_golden, rel_mse
+from oracle import ldt_oracle as O
+
+TOL = 1e-10
+
+
+def test_time_embedding():
+    a, sds = load_golden("time_embedding")
+    sd = {"TimeEmbedding." + k: v for k, v in sds["w"].items()}
+    assert torch.equal(O.sinusoid(a["t"], 256), a["sinusoid"])          # Q5, bit-exact
+    out = O.time_embedding(sd, "TimeEmbedding", a["t"], 256)
+    assert rel_mse(out, a["out"]) < TOL
+
+
+def _blk_sd(sds):
+    return {"b." + k: v for k, v in sds["w"].items()}
+
+
+def test_resblock_self_q1_q2():
+    a, sds = load_golden("resblock_self")
+    out = O.residual_block(_blk_sd(sds), "b", a["x"], None, a["c"], int(a["heads"]))
+    assert rel_mse(out, a["out"]) < TOL
+
+
+def test_resblock_encoder_raw_kv():
+    a, sds = load_golden("resblock_encoder")
+    out = O.residual_block(_blk_sd(sds), "b", a["x"], a["x"], a["c"], int(a["heads"]))
+    assert rel_mse(out, a["out"]) < TOL
+    # Q2: K/V from the raw stream differs from K/V from the modulated stream
+    other = O.residual_block(_blk_sd(sds), "b", a["x"], None, a["c"], int(a["heads"]))
+    assert rel_mse(other, a["out"]) > 1e-6
+
+
+def test_resblock_cross():
+    a, sds = load_golden("resblock_cross")
+    out = O.residual_block(_blk_sd(sds), "b", a["x"], a["y"], a["c"], int(a["heads"]))
+    assert rel_mse(out, a["out"]) < TOL
+
+
+def test_resblock_decoder_affine_ln():
+    a, sds = load_golden("resblock_decoder")
+    sd = _blk_sd(sds)
+    assert rel_mse(O.residual_block(sd, "b", a["x"], a["y"], None, int(a["heads"])), a["out"]) < TOL
+    assert rel_mse(O.residual_block(sd, "b", a["x"], None, None, int(a["heads"])), a["out_self"]) < TOL
+
+
+def test_q1_head_merge_is_raw_reinterpret():
+    """A 'clean' head merge (permute heads back) must NOT match the reference."""
+    a, sds = load_golden("resblock_decoder")
+    sd = _blk_sd(sds)
+    H = int(a["heads"])
+    x = O.layer_norm(a["x"], sd["b.norm1.norm.weight"], sd["b.norm1.norm.bias"])
+    q = O.linear(sd, "b.fc_q", x); kv = O.linear(sd, "b.fc_kv", a["y"])
+    B, N, C = q.shape
+    k, v = kv[..., :C], kv[..., C:]
+    sp = lambda z: z.reshape(B, -1, H, C // H).permute(0, 2, 1, 3)
+    o = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * (C // H) ** -0.5, -1) @ sp(v)
+    clean = O.linear(sd, "b.fc_o", o.permute(0, 2, 1, 3).reshape(B, N, C))
+    raw = O.attention(sd, "b", x, a["y"], H)
+    assert rel_mse(clean, raw) > 1e-3
+
+
+def test_final_layer():
+    a, sds = load_golden("final_layer")
+    out = O.final_layer({"f." + k: v for k, v in sds["w"].items()}, "f", a["x"], a["c"])
+    assert rel_mse(out, a["out"]) < TOL
+
+
+def test_score_tiny(tiny_cfg):
+    a, sds = load_golden("score_tiny")
+    out = O.score_forward(sds["w"], tiny_cfg.score, a["x"], a["t"])
+    assert rel_mse(out, a["out"]) < TOL
+    outc = O.score_forward(sds["w"], tiny_cfg.score, a["x"], a["t"], condition=(a["pts_cond"], a["img_cond"]))
+    assert rel_mse(outc, a["out_cond"]) < TOL
+
+
+def test_vpsde_tables_bit_exact(tiny_cfg):
+    for N in (100, 1000):
+        a, _ = load_golden("vpsde_tables_N%d" % N)
+        tiny_cfg.sde.sample_N = N
+        sde = O.VPSDE(tiny_cfg.sde)
+        ts = torch.linspace(1.0, tiny_cfg.sde.sample_time_eps, N)
+        assert torch.equal(ts, a["timesteps"])
+        assert torch.equal(sde.betas, a["betas"]) and torch.equal(sde.alphas_cump, a["alphas_cump"])
+        assert torch.equal((ts * (N - 1) / 1.0).long(), a["idx"])
+        assert torch.equal(a["idx"], torch.arange(N - 1, -1, -1))        # Q7: idx == N-1-i
+        for name in ("var", "std", "g2", "f", "e2int_f"):
+            assert torch.equal(getattr(sde, name)(ts), a[name]), name
+        # hard part 4: var(1e-6) is exactly one fp32 ulp
+        assert float(a["var"][-1]) == float(np.float32(1.1920929e-07))
+    tiny_cfg.sde.sample_N = 50
+
+
+def test_trainer_sample_and_trajectory(tiny_cfg):
+    a, sds = load_golden("trainer_sample_tiny")
+    s, _ = load_golden("score_tiny")
+    score_sd = load_golden("score_tiny")[1]["w"]
+    N = int(a["N"])
+    assert N == tiny_cfg.sde.sample_N
+    # the recorded draws equal a fresh CPU generator seeded 1234 in the documented order
+    x0, noises = O.draw_noises(1234, *a["x0"].shape, N)
+    assert torch.equal(x0, a["x0"]) and torch.equal(torch.stack(noises), a["noises"])
+    rec = []
+    pts, eps = O.trainer_sample(score_sd, sds["c"], tiny_cfg, a["x0"], list(a["noises"]), record=rec)
+    # teacher-forced per-step check
+    sde = O.VPSDE(tiny_cfg.sde)
+    for j, i in enumerate(a["step_ids"].tolist()):
+        p = O.score_forward(score_sd, tiny_cfg.score, a["step_x"][j], a["step_t"][j])
+        assert rel_mse(p, a["step_params"][j]) < TOL, i
+    # free-running trajectory
+    for j, i in enumerate(a["step_ids"].tolist()):
+        assert rel_mse(rec[i][0], a["step_x"][j]) < 1e-8, i
+    assert rel_mse(eps, a["eps"]) < 1e-8
+    assert rel_mse(pts, a["points"]) < 1e-8
+
+
+def test_other_predictors(tiny_cfg):
+    a, _ = load_golden("other_predictors")
+    t, _ = load_golden("trainer_sample_tiny")
+    score_sd = load_golden("score_tiny")[1]["w"]
+    sde = O.VPSDE(tiny_cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, tt: O.score_forward(score_sd, tiny_cfg.score, x, tt))
+    for pred in ("reversediffusion", "eulermaruyama", "ddim"):
+        out = O.sample_discrete(sde, fn, t["x0"], list(t["noises"]), tiny_cfg.sde.sample_N, predictor=pred)
+        assert rel_mse(out, a[pred]) < 1e-8, pred
+
+
+def test_decoder(tiny_cfg):
+    a, _ = load_golden("decoder_tiny")
+    sd = load_golden("trainer_sample_tiny")[1]["c"]
+    out = O.compressor_decode(sd, tiny_cfg.compressor, a["given_eps"])
+    assert rel_mse(out, a["points"]) < TOL
+
+
+def test_encoder(tiny_cfg):
+    a, _ = load_golden("compressor_fwd_tiny")
+    sd = load_golden("trainer_sample_tiny")[1]["c"]
+    cc = tiny_cfg.compressor
+    T = cc.z_scales
+    # discrete stages: FPS indices, kNN index *sets*
+    fi = O.fps(a["pts"], T)
+    assert torch.equal(fi, a["fps_idx"].long())
+    assert rel_mse(O.square_distance(O.gather(a["pts"], fi), a["pts"]), a["sqdist"]) < TOL
+    ki = O.knn(a["pts"].shape[1] // T * 2, a["pts"], O.gather(a["pts"], fi))
+    assert torch.equal(ki.sort(-1)[0], a["knn_idx"].sort(-1)[0])
+    r = O.compressor_encode(sd, cc, a["pts"], list(a["post_noise"]))
+    assert rel_mse(r["centers"], a["centers"].transpose(1, 2) if a["centers"].shape[1] == 3 else a["centers"]) < TOL
+    assert rel_mse(torch.stack(r["mu"]), a["mu"]) < 1e-9
+    assert rel_mse(torch.stack(r["logvar"]), a["logvar"]) < 1e-9
+    assert rel_mse(r["all_eps"], a["all_eps"]) < 1e-9
+    assert rel_mse(r["set"], a["set"]) < 1e-9
+    assert abs(float(r["max"]) - float(a["max"])) < 1e-4 * abs(float(a["max"]))
+
+
+def test_fps_tie_break_and_start():
+    """Exact ties (duplicate points): index 0 is always first (sampling.cu:105-107); a tie goes to
+    the smaller (k % 512, k // 512) — the 512-thread strided scan + pairwise tree (:141-158)."""
+    p = torch.tensor([[[0., 0, 0], [1, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 2, 0]]])
+    idx = O.fps(p, 4)[0].tolist()
+    assert idx == [0, 4, 1, 3]
+    # n > 512: k=513 is scanned by thread 1, k=2 by thread 2 -> 513 wins the tie
+    q = torch.zeros(1, 600, 3)
+    q[0, 2] = torch.tensor([3., 0, 0]); q[0, 513] = torch.tensor([3., 0, 0])
+    assert O.fps(q, 2)[0].tolist() == [0, 513]
+
+
+def test_chamfer():
+    a, _ = load_golden("chamfer")
+    dl, dr = O.dist_chamfer(a["a"], a["b"])
+    assert rel_mse(dl, a["dl"]) < TOL and rel_mse(dr, a["dr"]) < TOL
+    assert rel_mse(O.chamfer_cd(a["a"], a["b"]), a["cd"]) < TOL
