@@ -1,0 +1,156 @@
+/*
+ * ldt_hip.h — C-ABI of libldt_hip.so: the MI355X (gfx950) kernels behind LDT's sampling hot path.
+ *
+ * The upstream reference (Negai-98/LDT) has NO native/FFI seam on this path — everything is torch.nn
+ * (SURVEY.md §8b).  The seam a drop-in keeps is the Python class surface (ldt_amd/: Score, Compressor,
+ * DiffusionVPSDE, Trainer); this library sits underneath it and each entry point below names the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes + a hipStream_t passed as void* (0 = default stream);
+ *     no torch types, no exceptions, no ownership transfer, no allocation of caller-visible memory.
+ *   - every function returns int: 0 ok; <0 argument/shape/alignment error (LDT_E*); >0 a hipError_t.
+ *     ldt_last_error() returns a thread-local message for the last non-zero status.
+ *   - bf16 buffers are uint16_t* (raw bfloat16 bits); matrices are row-major with explicit leading dims
+ *     in ELEMENTS; "token-major": activations are [rows = batch*tokens][channels].
+ *   - step-dependent operands (AdaLN tables, sampler coefficients, injected noise) are addressed as
+ *     base + (*step_ptr) * step_stride with step_ptr a DEVICE int, so one captured HIP graph of a single
+ *     reverse-SDE step can be replayed for every step (NULL step_ptr = step 0 / host step where given).
+ */
+#ifndef LDT_HIP_H
+#define LDT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDT_ABI_VERSION 1
+#define LDT_OK 0
+#define LDT_EARG (-1)    /* null / inconsistent argument */
+#define LDT_ESHAPE (-2)  /* unsupported shape */
+#define LDT_EALIGN (-3)  /* pointer / leading-dim alignment */
+#define LDT_MAX_BLOCKS 64
+
+int ldt_abi_version(void);
+const char* ldt_last_error(void);
+
+/* ---- packing ------------------------------------------------------------------------------------
+ * fp32 [rows][cols] (ld_src) -> bf16 [rows][cols_pad] (ld_dst), zero padded to cols_pad (multiple of 4).
+ * Used to pack Conv1d/Linear weights (out,in,1) once per weight version (after
+ * EMA.swap_parameters_with_ema, tools/utils.py:80-101) and to feed fp32 latents to the MFMA GEMM. */
+int ldt_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst,
+                      int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
+
+/* ---- token-linear layers: bf16 MFMA GEMM with fused epilogue --------------------------------------
+ * out[M,N] = epi( X[M,K] · W[N,K]^T + bias[N] ).  Replaces every 1x1 nn.Conv1d / nn.Linear on the path:
+ * model/layers.py:159-161 (fc_q, fc_kv, fc_o), :121-124 (MLP fc/out), model/scorenet/score.py:110 (ln_in),
+ * model/layers.py:239 (FinalLayer.ln) and the Compressor's twins.  K % 64 == 0 (pad), rows 16-B aligned. */
+enum ldt_epilogue {
+    LDT_EPI_F32 = 0,        /* out fp32 = acc + bias */
+    LDT_EPI_BF16 = 1,       /* out bf16 = acc + bias */
+    LDT_EPI_GELU_BF16 = 2,  /* out bf16 = gelu_erf(acc + bias)            (layers.py:127-129) */
+    LDT_EPI_RELU_BF16 = 3,  /* out bf16 = relu(acc + bias [+ skip bf16])  (Compressor/layers.py:115-160) */
+    LDT_EPI_RESID_F32 = 4   /* out fp32 = resid + gate[s,:] * (acc + bias) (layers.py:218-219; gate NULL = 1) */
+};
+int ldt_gemm_bf16(int32_t epilogue, const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw,
+                  const float* bias, void* out, int64_t ldo,
+                  const float* resid, int64_t ldr, const uint16_t* skip, int64_t ldskip,
+                  const float* gate, int64_t gate_sample_stride, int32_t rows_per_sample,
+                  const int32_t* step_ptr, int64_t gate_step_stride,
+                  int32_t M, int32_t N, int32_t K, void* stream);
+
+/* ---- LayerNorm(eps 1e-6) [+affine] [+AdaLN modulate] -> bf16 -----------------------------------------
+ * y = LN(x)[*w+b] * (1 + scale[s]) + shift[s].  tools/utils.py:127-133 + model/layers.py:136-137,218-219.
+ * shift/scale: fp32 [samples or 1][...] addressed base + step*mod_step_stride + sample*mod_sample_stride. */
+int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy,
+                           const float* w, const float* b, const float* shift, const float* scale,
+                           int64_t mod_sample_stride, int32_t rows_per_sample,
+                           const int32_t* step_ptr, int64_t mod_step_stride,
+                           int64_t M, int32_t C, void* stream);
+
+/* ---- fused multi-head attention ---------------------------------------------------------------------
+ * O[b,h,n,:] = softmax(Q K^T / sqrt(Dh)) V, heads at channel offset h*Dh of each row; output is the
+ * contiguous [B][H][Nq][Dh] buffer the reference reinterprets as (B,N,C) (model/layers.py:190-197, Q1).
+ * head_dim 32 or 64.  K and V share kv_batch_stride. */
+int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride,
+                      const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride,
+                      uint16_t* O, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream);
+
+/* ---- fp32 linear for the small precision-critical layers ---------------------------------------------
+ * C[M,N] = act_out( act_in(A[M,K]) · Bw[N,K]^T + bias ), fp32 FMA accumulate; out fp32 or bf16.
+ * TimeEmbedding.mlp (model/layers.py:17), adaLN Linear (:172,:238), K<=64 convs, MiniPointnet, prior heads. */
+enum ldt_act { LDT_ACT_NONE = 0, LDT_ACT_SILU = 1, LDT_ACT_RELU = 2, LDT_ACT_GELU = 3 };
+int ldt_sgemm(const float* A, int64_t lda, const float* Bw, int64_t ldb, const float* bias,
+              void* C, int64_t ldc, int32_t out_bf16, int32_t act_in, int32_t act_out,
+              int32_t M, int32_t N, int32_t K, void* stream);
+
+/* sinusoidal embedding of continuous t (model/layers.py:20-36): e[n][2*half] = [sin(t f) | cos(t f)];
+ * freq[half] is built by the host with the reference's fp32 expression (quirk Q5). */
+int ldt_sinusoid(const float* t, const float* freq, float* e, int32_t n, int32_t half, void* stream);
+
+/* ---- reverse-SDE predictor update (diffusion/diffusion_continuous.py:141-191) ---------------------------
+ * mode 0 = ancestral in the reference's op order (coef[step] = {beta, std, sqrt(1-beta), sqrt(beta)});
+ * mode 1 = folded x_mean = A x + B params, x = x_mean + C z (coef[step] = {A,B,C,0}).
+ * z = noise[step*noise_step_stride + i] if noise != NULL (parity mode: injected CPU draws), else Philox4x32-10
+ * keyed by (seed, step, elem_offset + i) — independent of how the batch is sharded across GPUs.
+ * step = *step_ptr if step_ptr else step_host.  x_out may alias x; x_mean_out may be NULL. */
+int ldt_sampler_step(const float* x, const float* params, const float* noise, int64_t noise_step_stride,
+                     float* x_out, float* x_mean_out, const float* coef,
+                     const int32_t* step_ptr, int32_t step_host, int32_t mode,
+                     int64_t n, int64_t elem_offset, uint64_t seed, void* stream);
+int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, uint64_t seed, void* stream);
+
+/* ---- Score network forward: model/scorenet/score.py:117-151 (Transformer path, unet False) ------------- */
+typedef struct ldt_score_plan {
+    int32_t hidden, heads, blocks, z_dim, z_pad, mlp_hidden, tokens, batch;
+    /* packed weights (bf16 [N][K] row-major, K padded) and fp32 biases */
+    const uint16_t* w_in;  const float* b_in;                       /* ln_in   [hidden][z_pad]       score.py:110 */
+    const uint16_t* w_qkv[LDT_MAX_BLOCKS]; const float* b_qkv[LDT_MAX_BLOCKS]; /* fc_q|fc_kv rows q,k,v [3h][h] layers.py:159-160 */
+    const uint16_t* w_o[LDT_MAX_BLOCKS];   const float* b_o[LDT_MAX_BLOCKS];   /* fc_o   [h][h]        layers.py:161 */
+    const uint16_t* w_up[LDT_MAX_BLOCKS];  const float* b_up[LDT_MAX_BLOCKS];  /* mlp.fc.0.0 [4h][h]   layers.py:121 */
+    const uint16_t* w_dn[LDT_MAX_BLOCKS];  const float* b_dn[LDT_MAX_BLOCKS];  /* mlp.out [h][4h]      layers.py:124 */
+    const uint16_t* w_out; const float* b_out;                      /* ln_out.ln [z_dim][hidden]     layers.py:239 */
+    /* AdaLN modulation: mod[step][sample][blocks*6*hidden + 2*hidden] fp32.  Block l at l*6*hidden:
+       shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp (layers.py:214); FinalLayer shift|scale (:244) last. */
+    const float* mod; int64_t mod_step_stride; int64_t mod_sample_stride;
+    /* workspace (caller-owned), M = batch*tokens rows */
+    uint16_t* xin;   /* [M][z_pad]       */
+    float*    X;     /* [M][hidden] fp32 residual stream */
+    uint16_t* Hb;    /* [M][hidden]      */
+    uint16_t* QKV;   /* [M][3*hidden]    */
+    uint16_t* Ob;    /* [M][hidden]  == [B][H][T][Dh] */
+    uint16_t* U;     /* [M][mlp_hidden]  */
+} ldt_score_plan;
+
+/* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */
+int ldt_score_forward(const ldt_score_plan* plan, const float* x, float* eps_out,
+                      const int32_t* step_ptr, void* stream);
+
+/* Same forward with a hipEvent pair around EVERY launch (same stream); returns summed milliseconds and launch
+ * counts per kernel class.  Synchronises the stream.  bench.py's live roofline measurement. */
+enum ldt_prof_class {
+    LDT_PROF_OTHER = 0,       /* cast/pad */
+    LDT_PROF_GEMM_IO = 1,     /* ln_in, FinalLayer.ln      (gemm<F32>)   */
+    LDT_PROF_LN = 2,          /* LayerNorm + AdaLN modulate               */
+    LDT_PROF_GEMM_QKV = 3,    /* fc_q|fc_kv                (gemm<BF16>)  */
+    LDT_PROF_ATTN = 4,        /* fused attention                          */
+    LDT_PROF_GEMM_RESID = 5,  /* fc_o, mlp.out + gate+res  (gemm<RESID>) */
+    LDT_PROF_GEMM_GELU = 6,   /* mlp.fc + GELU             (gemm<GELU>)  */
+    LDT_PROF_NCLASS = 7
+};
+int ldt_score_forward_profile(const ldt_score_plan* plan, const float* x, float* eps_out, const int32_t* step_ptr,
+                              float* ms_by_class, int32_t* launches_by_class, void* stream);
+
+/* The whole reverse-SDE loop (pc_sampling, diffusion_continuous.py:231-258 with corrector None): n_steps x
+ * [Score forward -> predictor update -> ++step].  x is updated in place, x_mean receives the last x_mean
+ * (denoise=True returns it, quirk Q8).  step_counter: device int32 scratch.  use_graph != 0 captures one
+ * step into a hipGraph and replays it. */
+int ldt_sample_loop(const ldt_score_plan* plan, float* x, float* x_mean, float* eps_tmp,
+                    const float* coef, int32_t mode, const float* noise, int64_t noise_step_stride,
+                    int64_t elem_offset, uint64_t seed, int32_t* step_counter, int32_t n_steps,
+                    int32_t use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

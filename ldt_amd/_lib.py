@@ -1,0 +1,84 @@
+"""ctypes binding of libldt_hip.so (C-ABI: include/ldt_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or an entry point
+fails, this raises — it never routes through PyTorch eager or the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldt_hip.so")
+ABI_VERSION = 1
+MAX_BLOCKS = 64
+
+EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = range(4)
+PROF_CLASSES = ("other", "gemm_io", "ln_modulate", "gemm_qkv", "attention", "gemm_resid", "gemm_gelu")
+
+_vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+
+
+class ScorePlan(C.Structure):
+    """Mirror of `ldt_score_plan` (include/ldt_hip.h)."""
+    _fields_ = (
+        [(n, _i32) for n in ("hidden", "heads", "blocks", "z_dim", "z_pad", "mlp_hidden", "tokens", "batch")]
+        + [("w_in", _vp), ("b_in", _vp)]
+        + [("w_qkv", _vp * MAX_BLOCKS), ("b_qkv", _vp * MAX_BLOCKS),
+           ("w_o", _vp * MAX_BLOCKS), ("b_o", _vp * MAX_BLOCKS),
+           ("w_up", _vp * MAX_BLOCKS), ("b_up", _vp * MAX_BLOCKS),
+           ("w_dn", _vp * MAX_BLOCKS), ("b_dn", _vp * MAX_BLOCKS)]
+        + [("w_out", _vp), ("b_out", _vp)]
+        + [("mod", _vp), ("mod_step_stride", _i64), ("mod_sample_stride", _i64)]
+        + [(n, _vp) for n in ("xin", "X", "Hb", "QKV", "Ob", "U")]
+    )
+
+
+# name -> argtypes; every symbol include/ldt_hip.h declares (tests/test_abi.py checks the two lists agree)
+SIGNATURES = {
+    "ldt_abi_version": [],
+    "ldt_last_error": [],
+    "ldt_cast_pad_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp],
+    "ldt_gemm_bf16": [_i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64,
+                      _i32, _i32, _i32, _vp],
+    "ldt_layernorm_modulate": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
+    "ldt_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ldt_sgemm": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ldt_sinusoid": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "ldt_sampler_step": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _u64, _vp],
+    "ldt_philox_normal": [_vp, _i64, _i64, _i32, _u64, _vp],
+    "ldt_score_forward": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp],
+    "ldt_score_forward_profile": [C.POINTER(ScorePlan), _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp],
+    "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, _i32, _vp],
+}
+
+_lib = None
+
+
+class LdtHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdtHipError(
+            "HIP extension %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or ldt_amd/csrc/build.sh).  There is no CPU fallback." % LIB_PATH)
+    h = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)           # AttributeError => stale .so
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "ldt_last_error" else C.c_int
+    if h.ldt_abi_version() != ABI_VERSION:
+        raise LdtHipError("libldt_hip.so ABI %d != binding ABI %d: rebuild" % (h.ldt_abi_version(), ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ldt_last_error()
+        raise LdtHipError("%s failed (status %d): %s" % (what or "libldt_hip", rc, (msg or b"").decode()))

@@ -1,0 +1,84 @@
+"""Host-side orchestration of one Set-Transformer `ResidualBlock` (reference model/layers.py:183-229) on the
+HIP kernels — used by the Compressor (d=128, 4 heads x 32).  The Score network has its own C++
+orchestrator (`ldt_score_forward`) because it runs 24 blocks x 1000 steps.
+
+    AdaLN block (Encoder, c = pos embedding):  x += g1 * Attn(mod(LN(x)), y) ; x += g2 * MLP(mod(LN(x)))
+    plain block (Decoder, c = None):           x += Attn(LN_affine(x), y)    ; x += MLP(LN_affine(x))
+
+K/V source y (quirk Q2): None -> the normalised/modulated x itself; otherwise the RAW tensor given.
+Head merge (quirk Q1): the attention kernel writes [B][H][N][Dh]; that buffer *is* the (B,N,C) raw reinterpret.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_SILU, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32
+from .layers import conv_w
+
+
+def _bf(w):
+    w = w.detach().float().contiguous()
+    return ops.cast_pad_bf16(w, ops.pad64(w.shape[1]))
+
+
+def pack_block(blk):
+    """bf16 operand panels + fp32 vectors of one ResidualBlock holder."""
+    C = blk.dim_in
+    wkv = conv_w(blk.fc_kv)
+    P = {
+        "C": C, "H": blk.num_heads,
+        "wq": _bf(conv_w(blk.fc_q)), "bq": blk.fc_q.bias.detach().float().contiguous(),
+        "wkv": _bf(wkv), "bkv": blk.fc_kv.bias.detach().float().contiguous(),
+        "wo": _bf(conv_w(blk.fc_o)), "bo": blk.fc_o.bias.detach().float().contiguous(),
+        "wup": _bf(conv_w(blk.mlp.fc[0][0])), "bup": blk.mlp.fc[0][0].bias.detach().float().contiguous(),
+        "wdn": _bf(conv_w(blk.mlp.out)), "bdn": blk.mlp.out.bias.detach().float().contiguous(),
+        "n1": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm1.affine),
+        "n2": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm2.affine),
+    }
+    if blk.dim_c is not None:
+        lin = blk.adaLN[1]
+        P["wada"], P["bada"] = lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
+    return P
+
+
+def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
+    """x fp32 [B*Nq, C] updated IN PLACE.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
+    c: fp32 [B, dim_c] condition (AdaLN) or None (affine LayerNorm block)."""
+    C, H = P["C"], P["H"]
+    if c is not None:
+        mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                  # [B, 6C]  layers.py:214
+        sh1, sc1, g1, sh2, sc2, g2 = (mod[:, i * C:(i + 1) * C] for i in range(6))
+        h = ops.layernorm_modulate(x, shift=sh1, scale=sc1, mod_sample_stride=6 * C, rows_per_sample=Nq)
+    else:
+        g1 = g2 = None
+        h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
+    q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
+    if y_bf16 is None:
+        y_bf16, Nk = h, Nq
+    kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                        # [B*Nk, 2C]: K | V  (layers.py:189)
+    a = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, Nq, Nk, C // H)            # [B,H,Nq,Dh] == (B*Nq, C) raw view
+    ops.gemm_bf16(a.view(B * Nq, C), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
+                  gate_sample_stride=6 * C if g1 is not None else 0, rows_per_sample=Nq)
+    if c is not None:
+        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=6 * C, rows_per_sample=Nq)
+    else:
+        h2 = ops.layernorm_modulate(x, w=P["n2"][0], b=P["n2"][1])
+    u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
+    ops.gemm_bf16(u, P["wdn"], P["bdn"], EPI_RESID_F32, out=x, resid=x, gate=g2,
+                  gate_sample_stride=6 * C if g2 is not None else 0, rows_per_sample=Nq)
+    return x
+
+
+def pack_final(fl):
+    lin = fl.adaLN[1]
+    return {"C": fl.ln.in_channels, "w": _bf(conv_w(fl.ln)), "b": fl.ln.bias.detach().float().contiguous(),
+            "n_out": fl.ln.out_channels,
+            "wada": lin.weight.detach().float().contiguous(), "bada": lin.bias.detach().float().contiguous()}
+
+
+def final_layer(P, x, B, N, c, out_dtype=torch.float32):
+    """FinalLayer with condition (layers.py:240-246): Conv(mod(LN(x)))."""
+    from ._lib import EPI_F32
+    C = P["C"]
+    mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                      # [B, 2C] shift | scale
+    h = ops.layernorm_modulate(x, shift=mod[:, :C], scale=mod[:, C:], mod_sample_stride=2 * C, rows_per_sample=N)
+    return ops.gemm_bf16(h, P["w"], P["b"], EPI_F32 if out_dtype == torch.float32 else EPI_BF16, n=P["n_out"])

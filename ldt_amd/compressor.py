@@ -1,0 +1,230 @@
+"""`Compressor` — the attention-based point-cloud set-VAE (reference: model/Compressor/Network.py:104-285,
+model/Compressor/layers.py), MI355X path.
+
+Same constructor / parameter tree / methods as the reference: `forward(x)` (= encode + reconstruct,
+Network.py:235-249), `sample(shape, given_eps)` (= decode, :251-268), `init()` (:163-165), plus the aliases
+`encode` / `decode` that BASELINE.json's north-star names.  All arithmetic runs in libldt_hip.so.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU
+from .blocks import final_layer, pack_block, pack_final, residual_block
+from .layers import ActNorm, FinalLayer, LabelEmbedding, MLP, ResidualBlock, _Holder, conv_w, params_fingerprint
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class InitialSet(_Holder):
+    """model/Compressor/layers.py:12-25 with max_outputs set: a learned (max_outputs, dim) query set."""
+
+    def __init__(self, dim_seed, max_outputs):
+        super().__init__()
+        if max_outputs is None:
+            raise NotImplementedError("mixture-of-Gaussians InitialSet (max_outputs=None) is not on the shipped path")
+        self.dim_seed, self.max_outputs = dim_seed, max_outputs
+        self.prior = nn.Parameter(torch.rand((max_outputs, dim_seed), requires_grad=True))
+
+
+class ConvBNReLU1D(_Holder):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.act = nn.ReLU(inplace=True)
+        self.net = nn.Sequential(nn.Conv1d(in_channels, out_channels, 1), nn.BatchNorm1d(out_channels), self.act)
+
+
+class ConvBNReLURes1D(_Holder):
+    def __init__(self, channel):
+        super().__init__()
+        self.act = nn.ReLU(inplace=True)
+        self.net1 = nn.Sequential(nn.Conv1d(channel, channel, 1), nn.BatchNorm1d(channel), self.act)
+        self.net2 = nn.Sequential(nn.Conv1d(channel, channel, 1))
+
+
+class PreExtraction(_Holder):
+    def __init__(self, channels, out_channels):
+        super().__init__()
+        self.transfer = ConvBNReLU1D(3 + 2 * channels, out_channels)
+        self.operation = nn.Sequential(ConvBNReLURes1D(out_channels))
+
+
+class LocalGrouper(_Holder):
+    """model/Compressor/layers.py:271-287 (use_xyz=True)."""
+
+    def __init__(self, in_channels, use_xyz=True, normalize="anchor"):
+        super().__init__()
+        if not use_xyz or normalize is None or normalize.lower() != "anchor":
+            raise NotImplementedError("LocalGrouper: only use_xyz=True, normalize='anchor' (shipped cluster_norm) is built")
+        self.normalize = "anchor"
+        self.affine_alpha = nn.Parameter(torch.ones([1, 1, 1, in_channels + 3]))
+        self.affine_beta = nn.Parameter(torch.zeros([1, 1, 1, in_channels + 3]))
+        self.extraction = PreExtraction(in_channels, in_channels)
+
+
+class MiniPointnet(_Holder):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.conv1 = nn.Conv1d(input_dim, 128, 1)
+        self.conv2 = nn.Conv1d(128, 256, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.fc = nn.Linear(256, output_dim)
+
+
+class Encoder(_Holder):
+    def __init__(self, dim_in, p_dim, num_heads, norm, mlp_ratio=4.0, num_layers=1):
+        super().__init__()
+        self.atts = nn.ModuleList([ResidualBlock(dim_in, dim_in, p_dim, num_heads, norm, mlp_ratio)
+                                   for _ in range(num_layers)])
+        self.conv_out = FinalLayer(dim_in, dim_in, p_dim, norm)
+
+
+class DecoderBlock(_Holder):
+    def __init__(self, dim_in, dim_z, num_heads, norm, mlp_ratio=4.0, min_sigma=-30., act=None, c_dim=None):
+        super().__init__()
+        if c_dim is not None:
+            raise NotImplementedError("class-conditional decoder blocks are not on the shipped path")
+        self.min_sigma = min_sigma
+        self.att = ResidualBlock(dim_in, dim_in, c_dim, num_heads, norm, mlp_ratio, act=act)
+        self.prior = nn.Sequential(nn.SiLU(), nn.Conv1d(dim_in, 2 * dim_z, 1))
+        self.att1 = ResidualBlock(dim_in, dim_in, c_dim, num_heads, norm, mlp_ratio, act=act)
+        self.ln = nn.Conv1d(dim_z, dim_in, 1)
+
+
+# ----------------------------------------------------------------------------- Compressor
+class Compressor(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.input_dim = cfg.input_dim
+        self.max_outputs = cfg.max_outputs
+        self.n_layers = cfg.n_layers
+        self.z_dim = cfg.z_dim
+        self.hidden_dim = cfg.hidden_dim
+        self.num_heads = cfg.num_heads
+        self.norm = cfg.norm
+        self.z_scales = cfg.z_scales
+        self.p_dim = cfg.p_dim
+        self.outsize = cfg.outsize
+        self.mlp_ratio = cfg.mlp_ratio
+        self.min_sigma = cfg.min_sigma
+        self.encoder_layers = cfg.encoder_layers
+        self.norm_input = cfg.norm_input
+        self.pre_group = cfg.pre_group
+        self.class_condition = cfg.class_condition
+        if cfg.norm_input or cfg.pre_group or cfg.class_condition or cfg.pos_embedding == "mlp" or not cfg.ActNorm \
+                or cfg.decoder_act is not None or cfg.encoder_dropout_p or cfg.decoder_dropout_p or not cfg.AdaLN:
+            raise NotImplementedError("Compressor option outside the shipped configuration "
+                                      "(norm_input/pre_group/class_condition/pos_embedding=mlp/ActNorm off/decoder_act/dropout)")
+        self.input = nn.Conv1d(self.input_dim, self.hidden_dim, 1)
+        self.ActNorm = cfg.ActNorm
+        self.conv_in = ActNorm(self.hidden_dim, self.z_scales, feature_type=cfg.ActNorm)
+        self.encoder = nn.ModuleList()
+        self.decoder = nn.ModuleList()
+        self.upsample = nn.ModuleList()
+        self.group = LocalGrouper(self.hidden_dim, True, normalize=cfg.cluster_norm)
+        self.pos_embedding = MiniPointnet(3, self.p_dim)
+        self.label_dim = None
+        for i in range(self.n_layers):
+            self.encoder.append(Encoder(self.hidden_dim, self.p_dim, self.num_heads, norm=self.norm,
+                                        num_layers=self.encoder_layers, mlp_ratio=self.mlp_ratio))
+            self.decoder.append(DecoderBlock(self.hidden_dim, cfg.z_dim, self.num_heads, norm=self.norm,
+                                             mlp_ratio=self.mlp_ratio, min_sigma=self.min_sigma, act=cfg.decoder_act,
+                                             c_dim=self.label_dim))
+        self.output = nn.Conv1d(self.hidden_dim, 3, 1)
+        self.init_set = InitialSet(self.hidden_dim, self.max_outputs)
+        self._pack, self._pack_key = None, None
+        self.decode_chunk = 128          # samples per decode pass (activations ~7 MB/sample at 2048 points)
+
+    def init(self):
+        """Network.py:163-165 — marks ActNorm initialised (call after loading a checkpoint)."""
+        self.conv_in.init()
+
+    # ------------------------------------------------------------------ packing
+    def _device(self):
+        return self.input.weight.device
+
+    def packed(self):
+        key = params_fingerprint(self) + tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        if self._device().type != "cuda":
+            raise RuntimeError("Compressor parameters are on %s: the HIP path needs them on the GPU" % self._device())
+        f32 = lambda t: t.detach().float().contiguous()
+        with torch.no_grad():
+            P = {"dec": [], "enc": []}
+            for d in self.decoder:
+                P["dec"].append({
+                    "att1": pack_block(d.att1), "att": pack_block(d.att),
+                    "w_ln": f32(conv_w(d.ln)), "b_ln": f32(d.ln.bias),
+                    "w_prior": f32(conv_w(d.prior[1])), "b_prior": f32(d.prior[1].bias)})
+            for e in self.encoder:
+                P["enc"].append({"atts": [pack_block(a) for a in e.atts], "out": pack_final(e.conv_out)})
+            P["w_out"], P["b_out"] = f32(conv_w(self.output)), f32(self.output.bias)
+            P["w_input"], P["b_input"] = f32(conv_w(self.input)), f32(self.input.bias)
+            P["prior"] = f32(self.init_set.prior)
+        self._pack, self._pack_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ decode (Network.py:251-268)
+    @torch.no_grad()
+    def sample(self, shape, given_eps=None, keep_mask=None):
+        """Top-down generation: given_eps (B, tokens, n_layers*z_dim) -> points (B, N, 3)."""
+        B, num_points = shape[0], shape[1]
+        num_points = self.outsize if num_points is None else num_points
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("Compressor.sample: parameters on %s; the HIP path has no CPU fallback" % dev)
+        # InitialSet.forward draws B randperms on the CPU generator even when every row is kept (quirk Q9,
+        # Compressor/ops.py:12): keep the generator stream aligned with the reference.
+        if keep_mask is None:
+            presence = [torch.randperm(self.max_outputs) < num_points for _ in range(B)]
+            keep_mask = torch.stack(presence, 0) if num_points != self.max_outputs else None
+        if given_eps is None:                                            # Network.py:259-260
+            given_eps = torch.randn((B, self.z_scales, self.n_layers * self.z_dim)).to(dev)
+        eps = given_eps.to(dev, torch.float32).contiguous()
+        P = self.packed()
+        out = torch.empty((B, num_points, 3), dtype=torch.float32, device=dev)
+        for b0 in range(0, B, self.decode_chunk):
+            b1 = min(B, b0 + self.decode_chunk)
+            km = None if keep_mask is None else keep_mask[b0:b1]
+            out[b0:b1] = self._decode_chunk(P, eps[b0:b1], num_points, km)
+        return self.postprocess(out)
+
+    def _initial_set(self, P, Bc, num_points, keep_mask):
+        """Compressor/layers.py:26-37: the learned prior rows, token-major fp32 [Bc*N, C]."""
+        prior = P["prior"]
+        if keep_mask is None:
+            return prior.unsqueeze(0).expand(Bc, -1, -1).reshape(Bc * num_points, -1).contiguous()
+        km = keep_mask.to(prior.device)
+        return torch.stack([prior[km[b]] for b in range(Bc)], 0).reshape(Bc * num_points, -1).contiguous()
+
+    def _decoder_level(self, Pd, o, eps_j, Bc, N, T):
+        """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j))."""
+        zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
+        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T)
+
+    def _decode_chunk(self, P, eps, N, keep_mask):
+        Bc, T, _ = eps.shape
+        o = self._initial_set(P, Bc, N, keep_mask)
+        e2 = eps.view(Bc * T, -1)
+        for j in range(self.n_layers):                                             # reversed(self.decoder), :263
+            Pd = P["dec"][self.n_layers - 1 - j]
+            self._decoder_level(Pd, o, e2[:, self.z_dim * j: self.z_dim * (j + 1)], Bc, N, T)
+        return ops.sgemm(o, P["w_out"], P["b_out"]).view(Bc, N, 3)                 # Conv1d C -> 3, :266
+
+    @staticmethod
+    def postprocess(x):
+        if x.shape[-1] != 3:
+            raise NotImplementedError("only xyz outputs (ShapeNet) are on the shipped path")   # Network.py:271-279
+        return x
+
+    # aliases named by BASELINE.json's north-star
+    def decode(self, given_eps, num_points=None):
+        return self.sample((given_eps.shape[0], num_points), given_eps=given_eps)
+
+    def encode(self, x, **kw):
+        return self.forward(x, **kw)["all_eps"]
+
+    def forward(self, x, num_points=None, label=None):
+        raise NotImplementedError("Compressor.forward (encode) lands with the FPS/kNN kernels")

@@ -1,0 +1,247 @@
+// C-ABI of libldt_hip.so (include/ldt_hip.h): argument marshalling, error reporting, and the two
+// host-side orchestrators that enqueue the whole Score forward / reverse-SDE loop on one HIP stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/ldt_hip.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void ldt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int ldt_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ldt_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return LDT_OK;
+}
+extern "C" const char* ldt_last_error(void) { return g_err; }
+extern "C" int ldt_abi_version(void) { return LDT_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------ internal launchers
+#define BF(p) reinterpret_cast<const bf16_t*>(p)
+#define BFM(p) reinterpret_cast<bf16_t*>(p)
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define TRY(expr)                   \
+    do {                            \
+        const int _rc = (expr);     \
+        if (_rc != LDT_OK) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------ primitive ops
+extern "C" int ldt_cast_pad_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows,
+                                 int32_t cols, int32_t cols_pad, void* stream) {
+    LDT_REQUIRE(src && dst, LDT_EARG, "cast_pad: null pointer");
+    return ldt_cast_pad_launch(src, ld_src, BFM(dst), ld_dst, rows, cols, cols_pad, ST(stream));
+}
+
+extern "C" int ldt_gemm_bf16(int32_t epilogue, const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw,
+                             const float* bias, void* out, int64_t ldo, const float* resid, int64_t ldr,
+                             const uint16_t* skip, int64_t ldskip, const float* gate, int64_t gate_sample_stride,
+                             int32_t rows_per_sample, const int32_t* step_ptr, int64_t gate_step_stride,
+                             int32_t M, int32_t N, int32_t K, void* stream) {
+    LDT_REQUIRE(X && W && out, LDT_EARG, "gemm: null pointer");
+    GemmArgs a{BF(X), ldx, BF(W), ldw, bias, out, ldo, resid, ldr, BF(skip), ldskip, gate, gate_sample_stride,
+               rows_per_sample, step_ptr, gate_step_stride, M, N, K};
+    return ldt_gemm_launch(epilogue, &a, ST(stream));
+}
+
+extern "C" int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, const float* w,
+                                      const float* b, const float* shift, const float* scale,
+                                      int64_t mod_sample_stride, int32_t rows_per_sample, const int32_t* step_ptr,
+                                      int64_t mod_step_stride, int64_t M, int32_t C, void* stream) {
+    LDT_REQUIRE(x && y, LDT_EARG, "ln: null pointer");
+    LnArgs a{x, ldx, BFM(y), ldy, w, b, shift, scale, mod_sample_stride, rows_per_sample, step_ptr, mod_step_stride, M, C};
+    return ldt_ln_launch(&a, ST(stream));
+}
+
+extern "C" int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride, const uint16_t* K,
+                                 int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride, uint16_t* O,
+                                 int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream) {
+    LDT_REQUIRE(Q && K && V && O, LDT_EARG, "attention: null pointer");
+    AttnArgs a{BF(Q), ldq, q_batch_stride, BF(K), ldk, kv_batch_stride, BF(V), ldv, BFM(O), B, H, Nq, Nk,
+               1.4426950408889634f / sqrtf((float)head_dim)};
+    return ldt_attn_launch(&a, head_dim, ST(stream));
+}
+
+extern "C" int ldt_sgemm(const float* A, int64_t lda, const float* Bw, int64_t ldb, const float* bias, void* C,
+                         int64_t ldc, int32_t out_bf16, int32_t act_in, int32_t act_out, int32_t M, int32_t N,
+                         int32_t K, void* stream) {
+    SgemmArgs a{A, lda, Bw, ldb, bias, C, ldc, out_bf16, act_in, act_out, M, N, K};
+    return ldt_sgemm_launch(&a, ST(stream));
+}
+
+extern "C" int ldt_sinusoid(const float* t, const float* freq, float* e, int32_t n, int32_t half, void* stream) {
+    LDT_REQUIRE(t && freq && e, LDT_EARG, "sinusoid: null pointer");
+    return ldt_sinusoid_launch(t, freq, e, n, half, ST(stream));
+}
+
+extern "C" int ldt_sampler_step(const float* x, const float* params, const float* noise, int64_t noise_step_stride,
+                                float* x_out, float* x_mean_out, const float* coef, const int32_t* step_ptr,
+                                int32_t step_host, int32_t mode, int64_t n, int64_t elem_offset, uint64_t seed,
+                                void* stream) {
+    StepArgs a{x, params, noise, x_out, x_mean_out, coef, step_ptr, step_host, mode, n, elem_offset, noise_step_stride,
+               (uint32_t)seed, (uint32_t)(seed >> 32)};
+    return ldt_sampler_step_launch(&a, ST(stream));
+}
+
+extern "C" int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, uint64_t seed, void* stream) {
+    LDT_REQUIRE(out, LDT_EARG, "philox_normal: null pointer");
+    return ldt_philox_normal_launch(out, n, elem_offset, step, (uint32_t)seed, (uint32_t)(seed >> 32), ST(stream));
+}
+
+// ------------------------------------------------------------------------------ Score forward
+static int check_plan(const ldt_score_plan* p) {
+    LDT_REQUIRE(p, LDT_EARG, "score: null plan");
+    LDT_REQUIRE(p->blocks > 0 && p->blocks <= LDT_MAX_BLOCKS, LDT_ESHAPE, "score: blocks=%d out of range", p->blocks);
+    LDT_REQUIRE(p->hidden > 0 && p->heads > 0 && p->hidden % p->heads == 0, LDT_ESHAPE, "score: hidden %% heads");
+    const int dh = p->hidden / p->heads;
+    LDT_REQUIRE(dh == 32 || dh == 64, LDT_ESHAPE, "score: head dim %d not built (32, 64)", dh);
+    LDT_REQUIRE(p->hidden % 64 == 0 && p->mlp_hidden % 64 == 0 && p->z_pad % 64 == 0 && p->z_pad >= p->z_dim, LDT_ESHAPE,
+                "score: hidden/mlp_hidden/z_pad must be multiples of 64");
+    LDT_REQUIRE(p->z_dim % 4 == 0, LDT_ESHAPE, "score: z_dim %% 4");
+    LDT_REQUIRE(p->tokens > 0 && p->batch > 0, LDT_ESHAPE, "score: empty batch");
+    LDT_REQUIRE(p->w_in && p->w_out && p->mod && p->xin && p->X && p->Hb && p->QKV && p->Ob && p->U, LDT_EARG, "score: null buffer in plan");
+    for (int l = 0; l < p->blocks; ++l)
+        LDT_REQUIRE(p->w_qkv[l] && p->w_o[l] && p->w_up[l] && p->w_dn[l], LDT_EARG, "score: block %d weights missing", l);
+    return LDT_OK;
+}
+
+// Optional per-launch HIP-event timing (bench.py's live roofline measurement): events are recorded on the
+// SAME stream the kernels run on, bracketing every launch; elapsed times are summed per kernel class.
+struct Prof {
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;      // 2 per launch
+    std::vector<int> cls;
+    void begin(int c) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev.push_back(a); ev.push_back(b); cls.push_back(c); (void)hipEventRecord(a, s); }
+    void end() { (void)hipEventRecord(ev.back(), s); }
+};
+#define LAUNCH(cls_, expr)                \
+    do {                                  \
+        if (prof) prof->begin(cls_);      \
+        const int _rc = (expr);           \
+        if (prof) prof->end();            \
+        if (_rc != LDT_OK) return _rc;    \
+    } while (0)
+
+static int score_forward_impl(const ldt_score_plan* p, const float* x, float* eps_out, const int32_t* step_ptr,
+                              hipStream_t s, Prof* prof) {
+    TRY(check_plan(p));
+    LDT_REQUIRE(x && eps_out, LDT_EARG, "score: null x/out");
+    const int D = p->hidden, T = p->tokens, M = p->batch * p->tokens, F = p->mlp_hidden;
+    const long sstr = p->mod_sample_stride, tstr = p->mod_step_stride;
+    // ln_in (score.py:136-137): latents fp32 -> bf16 (K padded) -> X fp32
+    LAUNCH(LDT_PROF_OTHER, ldt_cast_pad_launch(x, p->z_dim, BFM(p->xin), p->z_pad, M, p->z_dim, p->z_pad, s));
+    {
+        GemmArgs g{BF(p->xin), p->z_pad, BF(p->w_in), p->z_pad, p->b_in, p->X, D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, p->z_pad};
+        LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &g, s));
+    }
+    for (int l = 0; l < p->blocks; ++l) {                       // score.py:148-149, layers.py:212-219
+        const float* m = p->mod + (long)l * 6 * D;              // shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
+        LnArgs n1{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
+        LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n1, s));
+        GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
+        LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+        AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
+                    BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
+        LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
+        LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
+        LnArgs n2{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m + 3 * D, m + 4 * D, sstr, T, step_ptr, tstr, M, D};
+        LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n2, s));
+        GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, p->b_up[l], p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, F, D};
+        LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_launch(LDT_EPI_GELU_BF16, &gu, s));
+        GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F};
+        LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
+    }
+    {                                                           // FinalLayer (layers.py:240-248)
+        const float* m = p->mod + (long)p->blocks * 6 * D;
+        LnArgs nf{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
+        LAUNCH(LDT_PROF_LN, ldt_ln_launch(&nf, s));
+        GemmArgs gf{BF(p->Hb), D, BF(p->w_out), D, p->b_out, eps_out, p->z_dim, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, p->z_dim, D};
+        LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &gf, s));
+    }
+    return LDT_OK;
+}
+
+extern "C" int ldt_score_forward(const ldt_score_plan* p, const float* x, float* eps_out, const int32_t* step_ptr, void* stream) {
+    return score_forward_impl(p, x, eps_out, step_ptr, ST(stream), nullptr);
+}
+
+extern "C" int ldt_score_forward_profile(const ldt_score_plan* p, const float* x, float* eps_out, const int32_t* step_ptr,
+                                         float* ms_by_class, int32_t* launches_by_class, void* stream) {
+    LDT_REQUIRE(ms_by_class && launches_by_class, LDT_EARG, "score_profile: null output");
+    Prof prof{ST(stream), {}, {}};
+    const int rc = score_forward_impl(p, x, eps_out, step_ptr, ST(stream), &prof);
+    (void)hipStreamSynchronize(ST(stream));
+    for (int c = 0; c < LDT_PROF_NCLASS; ++c) { ms_by_class[c] = 0.f; launches_by_class[c] = 0; }
+    for (size_t i = 0; i < prof.cls.size(); ++i) {
+        float ms = 0.f;
+        if (rc == LDT_OK && hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]) == hipSuccess) {
+            ms_by_class[prof.cls[i]] += ms;
+            launches_by_class[prof.cls[i]] += 1;
+        }
+        (void)hipEventDestroy(prof.ev[2 * i]);
+        (void)hipEventDestroy(prof.ev[2 * i + 1]);
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ reverse-SDE loop
+static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef, int mode,
+                        const float* noise, long noise_step_stride, long elem_offset, uint64_t seed, int* step_counter,
+                        hipStream_t s) {
+    TRY(score_forward_impl(p, x, eps_tmp, step_counter, s, nullptr));
+    const long n = (long)p->batch * p->tokens * p->z_dim;
+    StepArgs st{x, eps_tmp, noise, x, x_mean, coef, step_counter, 0, mode, n, elem_offset, noise_step_stride,
+                (uint32_t)seed, (uint32_t)(seed >> 32)};
+    TRY(ldt_sampler_step_launch(&st, s));
+    return ldt_advance_step_launch(step_counter, s);
+}
+
+extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef,
+                               int32_t mode, const float* noise, int64_t noise_step_stride, int64_t elem_offset,
+                               uint64_t seed, int32_t* step_counter, int32_t n_steps, int32_t use_graph, void* stream) {
+    TRY(check_plan(p));
+    LDT_REQUIRE(x && x_mean && eps_tmp && coef && step_counter && n_steps > 0, LDT_EARG, "sample_loop: null pointer / n_steps");
+    hipStream_t s = ST(stream);
+    hipError_t e = hipMemsetAsync(step_counter, 0, sizeof(int), s);
+    if (e != hipSuccess) { ldt_set_error("sample_loop: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i)
+            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, s));
+        return LDT_OK;
+    }
+    // one step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { ldt_set_error("sample_loop: begin capture: %s", hipGetErrorString(e)); return (int)e; }
+    const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, s);
+    e = hipStreamEndCapture(s, &graph);
+    if (rc != LDT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(e)); return (int)e; }
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(graph); ldt_set_error("sample_loop: instantiate: %s", hipGetErrorString(e)); return (int)e; }
+    int status = LDT_OK;
+    for (int i = 0; i < n_steps; ++i) {
+        e = hipGraphLaunch(exec, s);
+        if (e != hipSuccess) { ldt_set_error("sample_loop: graph launch %d: %s", i, hipGetErrorString(e)); status = (int)e; break; }
+    }
+    // the exec must outlive its in-flight launches
+    (void)hipStreamSynchronize(s);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    return status;
+}

@@ -1,0 +1,199 @@
+// bf16 MFMA GEMM for the token-linear layers of the LDT hot path (gfx950 / MI355X).
+//
+//   Y[M,N] = epilogue( X[M,K] (bf16, row-major, ldx) · W[N,K]^T (bf16, row-major, ldw) + bias[N] )
+//
+// This is every 1x1 Conv1d / Linear on the path (reference: model/layers.py:159-161 fc_q/fc_kv/fc_o,
+// :121-124 MLP fc/out, model/scorenet/score.py:110,112 ln_in/ln_out.ln; Compressor twins).  A Conv1d
+// weight (out,in,1) is already the [N][K] K-contiguous operand MFMA wants, so nothing is transposed.
+//
+// Structure (v1, "2-phase" of the CDNA4 guide): 128x128x64 tile, 256 threads = 2x2 waves of 64x64,
+// mfma_f32_16x16x32_bf16 with the operands SWAPPED (D[n][m] = W·X^T) so that each lane ends up with 4
+// consecutive output columns of one row -> 16-B fp32 / 8-B bf16 epilogue accesses.  Both operand tiles
+// are staged HBM->LDS with global_load_lds (16 B/lane, LDS image lane-linear), double-buffered; the
+// LDS bank-conflict swizzle chunk' = chunk ^ ((row>>1)&7) is applied on the SOURCE address and on the
+// ds_read address (both-sides rule).  The workgroup->tile map is XCD-aware (blocks that share an XCD's
+// L2 walk one row-panel of X across the N tiles of W).
+//
+// Fused epilogues (template EPI):
+//   EPI_F32        out fp32  = acc + bias
+//   EPI_BF16       out bf16  = acc + bias
+//   EPI_GELU_BF16  out bf16  = gelu_erf(acc + bias)                       (MLP up, layers.py:127-129)
+//   EPI_RELU_BF16  out bf16  = relu(acc + bias [+ skip bf16])             (PreExtraction, Compressor/layers.py:115-160)
+//   EPI_RESID_F32  out fp32  = resid + gate[s,n] * (acc + bias)           (x + gate*(...), layers.py:218-219; gate may be null)
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * BK * 2)      // 16 KiB per operand per stage
+
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
+                                           int k0, char* lds_tile, int wave, int lane) {
+    // one operand tile = 128 rows x 128 B = 16 pieces of 1 KiB (8 rows each); 4 pieces per wave
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int piece = wave * 4 + p;
+        const int r = piece * 8 + (lane >> 3);
+        const int cdst = lane & 7;
+        const int csrc = cdst ^ ((r >> 1) & 7);
+        int grow = row0 + r;
+        grow = grow < nrows_total ? grow : nrows_total - 1;          // clamp: OOB rows are never stored
+        const bf16_t* src = g + (long)grow * ld + k0 + csrc * 8;
+        char* dst = lds_tile + piece * 1024;                          // wave-uniform; HW adds lane*16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [stage][X|W]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware bijective remap of the 1-D grid (blocks b, b+8, ... share an XCD's L2) ----
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / BK;
+    stage_tile(a.X, a.ldx, m0, a.M, 0, smem, wave, lane);
+    stage_tile(a.W, a.ldw, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lrow = lane & 15;
+    const int lchk = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        char* sx = smem + cur * 2 * TILE_BYTES;
+        char* sw = sx + TILE_BYTES;
+        if (kt + 1 < nk) {
+            char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nx, wave, lane);
+            stage_tile(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nx + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], xf[4];
+            const int c = ks * 4 + lchk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = wn * 64 + i * 16 + lrow;
+                wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + ((c ^ ((rw >> 1) & 7)) << 4));
+                const int rx = wm * 64 + i * 16 + lrow;
+                xf[i] = *reinterpret_cast<const bf16x8*>(sx + rx * 128 + ((c ^ ((rx >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds D[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)], r = 0..3 ----
+    const float* gate = a.gate;
+    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + lrow;
+        if (m >= a.M) continue;
+        const float* grow = nullptr;
+        if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + lchk * 4;
+            if (n >= a.N) continue;
+            f32x4 v = acc[ni][mi];
+            const bool full = (n + 3 < a.N);
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                if (full) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n); b[0] = t[0]; b[1] = t[1]; b[2] = t[2]; b[3] = t[3]; }
+                else for (int r = 0; r < 4; ++r) if (n + r < a.N) b[r] = a.bias[n + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += b[r];
+            if (EPI == EPI_F32) {
+                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
+                if (full) *reinterpret_cast<f32x4*>(o) = v;
+                else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
+            } else if (EPI == EPI_RESID_F32) {
+                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
+                const float* rs = a.resid + (long)m * a.ldr + n;
+                if (full) {
+                    f32x4 x = *reinterpret_cast<const f32x4*>(rs);
+                    if (grow) { const f32x4 g = *reinterpret_cast<const f32x4*>(grow + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = x[r] + g[r] * v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = x[r] + v[r];
+                    }
+                    *reinterpret_cast<f32x4*>(o) = x;
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = rs[r] + (grow ? grow[n + r] : 1.f) * v[r];
+                }
+            } else {
+                if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if (EPI == EPI_RELU_BF16) {
+                    if (a.skip) {
+                        const bf16_t* sk = a.skip + (long)m * a.lds_ + n;
+                        for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += (float)sk[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)m * a.ldo + n;
+                if (full) {
+                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(o) = pk;
+                } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
+            }
+        }
+    }
+}
+
+int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
+    LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, LDT_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+    LDT_REQUIRE(a->K % BK == 0, LDT_ESHAPE, "gemm: K=%d must be a multiple of %d (pad activations/weights)", a->K, BK);
+    LDT_REQUIRE(a->ldx % 8 == 0 && a->ldw % 8 == 0 && ldt_aligned16(a->X) && ldt_aligned16(a->W), LDT_EALIGN,
+                "gemm: X/W rows must be 16-byte aligned (ldx=%ld ldw=%ld)", a->ldx, a->ldw);
+    LDT_REQUIRE(a->ldx >= a->K && a->ldw >= a->K, LDT_ESHAPE, "gemm: leading dims smaller than K");
+    LDT_REQUIRE(a->ldo % 4 == 0 && ldt_aligned16(a->out), LDT_EALIGN, "gemm: out must be 16-byte aligned, ldo%%4==0 (ldo=%ld)", a->ldo);
+    if (epi == EPI_RESID_F32) {
+        LDT_REQUIRE(a->resid && a->ldr % 4 == 0 && ldt_aligned16(a->resid), LDT_EALIGN, "gemm: resid missing/misaligned");
+        LDT_REQUIRE(!a->gate || (a->rows_per_sample > 0 && ldt_aligned16(a->gate) && a->gate_sample_stride % 4 == 0 && a->gate_step_stride % 4 == 0),
+                    LDT_EARG, "gemm: gate needs rows_per_sample>0 and 16-byte aligned strides");
+    }
+    LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm: bias must be 16-byte aligned");
+    const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    dim3 grid(tiles), block(256);
+    switch (epi) {
+        case EPI_F32: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_F32>, grid, block, 0, stream, *a); break;
+        case EPI_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_BF16>, grid, block, 0, stream, *a); break;
+        case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_GELU_BF16>, grid, block, 0, stream, *a); break;
+        case EPI_RELU_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_RELU_BF16>, grid, block, 0, stream, *a); break;
+        case EPI_RESID_F32: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_RESID_F32>, grid, block, 0, stream, *a); break;
+        default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
+    }
+    return ldt_check_launch("gemm_bf16_nt");
+}

@@ -1,0 +1,63 @@
+// Internal argument blocks + launcher prototypes shared by the kernel files and api.hip.
+#pragma once
+#include "common.h"
+
+enum { EPI_F32 = 0, EPI_BF16 = 1, EPI_GELU_BF16 = 2, EPI_RELU_BF16 = 3, EPI_RESID_F32 = 4 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GELU = 3 };
+
+struct GemmArgs {
+    const bf16_t* X; long ldx;
+    const bf16_t* W; long ldw;
+    const float* bias;
+    void* out; long ldo;
+    const float* resid; long ldr;       // EPI_RESID_F32 (may alias out)
+    const bf16_t* skip; long lds_;      // EPI_RELU_BF16 optional skip
+    const float* gate;                  // [samples or 1][gate_sample_stride] fp32, nullable
+    long gate_sample_stride;            // 0 = one gate vector shared by every row
+    int rows_per_sample;
+    const int* step_ptr; long gate_step_stride;   // gate += *step_ptr * gate_step_stride (device-side step counter)
+    int M, N, K;
+};
+
+struct LnArgs {
+    const float* x; long ldx;
+    bf16_t* y; long ldy;
+    const float* w; const float* b;              // affine (decoder blocks), nullable
+    const float* shift; const float* scale;      // nullable (no modulation)
+    long mod_sample_stride; int rows_per_sample;
+    const int* step_ptr; long mod_step_stride;
+    long M; int C;
+};
+
+struct AttnArgs {
+    const bf16_t* Q; long ldq; long q_batch_stride;     // Q[b][n][h*Dh + d]
+    const bf16_t* K; long ldk; long kv_batch_stride;    // K[b][m][h*Dh + d]
+    const bf16_t* V; long ldv;                          // V[b][m][h*Dh + d] (same batch stride as K)
+    bf16_t* O;                                          // [B][H][Nq][Dh]
+    int B, H, Nq, Nk;
+    float scale_log2e;                                  // Dh^-0.5 * log2(e)
+};
+
+struct StepArgs {
+    const float* x; const float* params; const float* noise;
+    float* x_out; float* x_mean_out;
+    const float* coef; const int* step_ptr; int step_host; int mode;
+    long n; long elem_offset; long noise_step_stride;
+    uint32_t seed_lo, seed_hi;
+};
+
+struct SgemmArgs {
+    const float* A; long lda; const float* B; long ldb; const float* bias;
+    void* C; long ldc; int out_bf16; int act_in; int act_out;
+    int M, N, K;
+};
+
+int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
+int ldt_ln_launch(const LnArgs* a, hipStream_t s);
+int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);
+int ldt_cast_pad_launch(const float* src, long lds, bf16_t* dst, long ldd, long rows, int cols, int cols_pad, hipStream_t s);
+int ldt_sampler_step_launch(const StepArgs* a, hipStream_t s);
+int ldt_advance_step_launch(int* step_ptr, hipStream_t s);
+int ldt_philox_normal_launch(float* out, long n, long elem_offset, int step, uint32_t k0, uint32_t k1, hipStream_t s);
+int ldt_sinusoid_launch(const float* t, const float* freq, float* e, int n, int half, hipStream_t s);
+int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s);

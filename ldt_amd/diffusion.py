@@ -1,0 +1,168 @@
+"""VP-SDE and the discrete reverse-SDE sampler (reference: diffusion/diffusion_continuous.py).
+
+`DiffusionVPSDE` keeps the reference constructor (`args` = cfg.sde Namespace) and the members the path
+uses: `f, g2, var, std, e2int_f, betas, alpha, alphas_cump, N, sample_discrete(...)` (:626-678, :133-338).
+Schedule scalars are host-side fp32 tables computed with the reference's own op order (SURVEY hard
+part 4: var(1e-6) is exactly one ulp in fp32 and must not be recomputed with a different expf) and uploaded.
+
+`sample_discrete` has the reference signature.  Two execution paths, both on HIP kernels:
+  * fused loop — when `score_fn` is the bound `Trainer.score_fn` of an `ldt_amd.Score` (unconditional):
+    one `ldt_sample_loop` call = AdaLN table for all N steps, then N x (Score forward -> fused predictor
+    update with in-kernel Philox noise -> ++step), optionally replayed from one captured hipGraph;
+  * generic loop — any other `score_fn(t, x, label=, condition=) -> (score, params)` callable is driven
+    step by step from Python, the update still done by `ldt_sampler_step` (params, not score, feed it).
+Extra keyword-only arguments (not in the reference): `x0`, `noise` (inject the CPU draws for parity),
+`sample_offset` (global index of this rank's first sample, keeps Philox streams shard-invariant).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+PREDICTORS = ("reversediffusion", "ancestral", "eulermaruyama", "ddim")
+
+
+def make_diffusion(args):
+    if args.sde_type == "vpsde":
+        return DiffusionVPSDE(args)
+    raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % (args.sde_type,))
+
+
+class DiffusionVPSDE:
+    def __init__(self, args):
+        self.sigma2_0 = args.sigma2_0
+        self.sde_type = args.sde_type
+        self.time_eps = args.time_eps
+        self.sample_time_eps = args.sample_time_eps
+        self.beta_start = args.beta_start
+        self.beta_end = args.beta_end
+        self.train_N = args.train_N
+        if args.sample_mode == "discrete":
+            self.N = args.sample_N
+            self.betas = torch.from_numpy(np.linspace(self.beta_start / self.N, self.beta_end / self.N, self.N,
+                                                      dtype=np.float64)).to(torch.float32)
+            self.alpha = 1.0 - self.betas
+            self.alphas_cump = self.alpha.cumprod(dim=0)
+
+    # ---- schedule (tensor in, tensor out; any device) ------------------------------------------
+    def g2(self, t):
+        return self.beta_start + (self.beta_end - self.beta_start) * t
+
+    def f(self, t):
+        return -0.5 * self.g2(t)
+
+    def var(self, t):
+        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
+            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+
+    def std(self, t):
+        return torch.sqrt(self.var(t))
+
+    def e2int_f(self, t):
+        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
+
+    def discrete(self, idx):
+        return self.betas.index_select(0, idx), self.alpha.index_select(0, idx)
+
+    # ---- per-step coefficient table for ldt_sampler_step ------------------------------------------
+    def step_table(self, N, predictor, time_eps, probability_flow=False):
+        """-> (timesteps [N] fp32 CPU, coef [N,4] fp32 CPU, mode).  All scalars are produced on the CPU with
+        the reference's expressions (fp32 tensors), the folded forms in fp64 then rounded once."""
+        if predictor not in PREDICTORS:
+            raise NotImplementedError("preditor not Implemented")           # diffusion_continuous.py:328
+        ts = torch.linspace(1.0, time_eps, N)                               # :238
+        if predictor == "ancestral":                                        # :152-162 — exact op order on device
+            idx = (ts * (N - 1) / 1.0).long()
+            beta = self.betas[idx]
+            coef = torch.stack([beta, self.std(ts), torch.sqrt(1. - beta), torch.sqrt(beta)], 1)
+            return ts, coef.contiguous(), 0
+        t64 = ts.double()
+        std = self.std(ts).double()
+        if predictor == "reversediffusion":                                 # :141-150
+            dt = (1 - time_eps) / N
+            g2 = self.g2(t64); ff = self.f(t64)
+            k = 0.5 if probability_flow else 1.0
+            A = 1 - ff * dt
+            Bc = -g2 * k * dt / std                # x_mean = x - (f x - g2 k score) dt, score = -params/std
+            Cc = torch.zeros_like(g2) if probability_flow else torch.sqrt(g2) * np.sqrt(dt)
+        elif predictor == "eulermaruyama":                                  # :182-191
+            dt = -1.0 / N
+            g2 = self.g2(t64); ff = self.f(t64)
+            k = 0.5 if probability_flow else 1.0
+            A = 1 + ff * dt
+            Bc = g2 * k * dt / std
+            Cc = torch.zeros_like(g2) if probability_flow else torch.sqrt(g2) * np.sqrt(-dt)
+        else:                                                               # ddim :164-180 (sigma = 0)
+            idx = (ts * (N - 1) / 1.0).long()
+            at = self.alphas_cump[idx].double()
+            at_next = torch.where(idx - 1 < 0, torch.ones_like(at), self.alphas_cump[(idx - 1).clamp_min(0)].double())
+            A = at_next.sqrt() / at.sqrt()
+            Bc = -at_next.sqrt() * (1 - at).sqrt() / at.sqrt() + (1 - at_next).sqrt()
+            Cc = torch.zeros_like(at)
+        coef = torch.stack([A, Bc, Cc, torch.zeros_like(A)], 1).float()
+        return ts, coef.contiguous(), 1
+
+    # ---- the sampler --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,
+                        probability_flow, denoise, snr, device, condition=None, label=None, print_steps=None,
+                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None):
+        """Reverse-SDE predictor(-only) sampling, diffusion_continuous.py:133-338."""
+        if corrector is not None:
+            raise NotImplementedError("correctors (langevin / ancestral, :193-229) are scheduled next (SURVEY §8f)")
+        if predictor == "pndm":
+            raise NotImplementedError("PNDM (:260-316) is scheduled next (SURVEY §8f)")
+        if print_steps is not None:
+            raise NotImplementedError("print_steps trajectory dump (:239-257) is scheduled next")
+        ts, coef, mode = self.step_table(N, predictor, time_eps, probability_flow)
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("sample_discrete: device %s — the HIP path has no CPU fallback" % (device,))
+        # initial sample: CPU generator then copy, exactly like the reference (:237)
+        x = torch.randn((num_samples,) + tuple(shape)) if x0 is None else x0
+        x = x.to(dev, torch.float32).contiguous().clone()
+        if seed is None:                                       # Philox key from the (seedable) CPU generator
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+            assert noise.shape == (N,) + tuple(x.shape), "noise must be [N, B, tokens, z]"
+        coef_d = coef.to(dev)
+        elem_offset = int(sample_offset) * int(np.prod(shape))
+        nstride = x.numel() if noise is not None else 0
+        x_mean = torch.empty_like(x)
+        model = _fused_model(score_fn) if (condition is None and label is None) else None
+        if model is not None and record is None:
+            _, mod = model.time_table(ts.to(dev))                                   # AdaLN rows for every step
+            plan = model.plan(x.shape[0], x.shape[1], mod, model.n_mod, 0)          # shared by the batch
+            eps_tmp = torch.empty_like(x)
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            if use_graph is None:
+                use_graph = x.shape[0] * x.shape[1] <= 4096                          # launch-bound regime only
+            check(lib().ldt_sample_loop(ctypes.byref(plan), x.data_ptr(), x_mean.data_ptr(), eps_tmp.data_ptr(),
+                                        coef_d.data_ptr(), mode, ops._p(noise), nstride, elem_offset, seed,
+                                        counter.data_ptr(), N, int(bool(use_graph)), ops.stream_ptr()),
+                  "ldt_sample_loop")
+        else:
+            ts_d = ts.to(dev)
+            for i in range(N):
+                vec_t = torch.ones((num_samples,), device=dev) * ts_d[i]             # :243-244
+                _, params = score_fn(vec_t, x, label=label, condition=condition)
+                x_new = ops.sampler_step(x, params.contiguous(), coef_d, i, mode, noise=noise, noise_step_stride=nstride,
+                                         x_mean_out=x_mean, elem_offset=elem_offset, seed=seed)
+                if record is not None:
+                    record.append((x, params, x_mean.clone(), x_new))
+                x = x_new
+        return x_mean if denoise else x
+
+
+def _fused_model(score_fn):
+    """The `ldt_amd.Score` behind a bound `Trainer.score_fn`, else None."""
+    from .score import Score
+    owner = getattr(score_fn, "__self__", None)
+    model = getattr(owner, "model", None)
+    if isinstance(model, Score) and getattr(score_fn, "__func__", None) is getattr(type(owner), "score_fn", None):
+        return model
+    return None

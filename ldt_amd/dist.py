@@ -1,0 +1,31 @@
+"""Multi-GPU sharding of the sampling loop: one process per GPU, contiguous batch slices by GLOBAL
+sample index, no data-path collective inside the loop, ONE all-gather (RCCL over xGMI when the backend is
+"nccl"; gloo in the CPU tests) of the finished shapes at the end — SURVEY.md §8e.  The reference itself is
+single-GPU (README.md:53); this module is new."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(num_samples, rank, world_size):
+    """Contiguous slice [lo, hi) of rank `rank`; the batch is padded to a multiple of world_size so every
+    rank runs the same shapes (padding rows are dropped after the gather)."""
+    per = (num_samples + world_size - 1) // world_size
+    lo = rank * per
+    return lo, lo + per, per
+
+
+def all_gather_rows(local, num_samples):
+    """local [per, ...] on every rank -> [num_samples, ...] (same on every rank): the single collective."""
+    rank, ws = world()
+    if ws == 1:
+        return local[:num_samples]
+    local = local.contiguous()
+    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out[:num_samples]

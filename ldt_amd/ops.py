@@ -1,0 +1,141 @@
+"""Tensor-level wrappers over the C-ABI (ldt_amd/_lib.py).  PyTorch is used only for device
+memory and the current HIP stream; every arithmetic op below runs in libldt_hip.so."""
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RELU_BF16,
+                   EPI_RESID_F32, check, lib)
+
+__all__ = ["cast_pad_bf16", "gemm_bf16", "layernorm_modulate", "attention_fwd", "sgemm", "sinusoid",
+           "sampler_step", "philox_normal", "pad64", "stream_ptr"]
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def pad64(k):
+    return (k + 63) // 64 * 64
+
+
+def _need(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.LdtHipError("%s must be a device tensor (got %s): the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def _rowmajor(t, name):
+    if t.stride(-1) != 1:
+        raise ValueError("%s must be contiguous in its last dim" % name)
+
+
+def cast_pad_bf16(src, cols_pad=None, out=None):
+    """fp32 [rows, cols] -> bf16 [rows, cols_pad] zero padded."""
+    _need(src, torch.float32, "src")
+    src2 = src.reshape(-1, src.shape[-1])
+    _rowmajor(src2, "src")
+    rows, cols = src2.shape
+    cols_pad = cols_pad or (cols + 3) // 4 * 4
+    if out is None:
+        out = torch.empty((rows, cols_pad), dtype=torch.bfloat16, device=src.device)
+    check(lib().ldt_cast_pad_bf16(_p(src2), src2.stride(0), _p(out), out.stride(0), rows, cols, cols_pad, stream_ptr()),
+          "ldt_cast_pad_bf16")
+    return out
+
+
+def gemm_bf16(x, w, bias=None, epilogue=EPI_BF16, out=None, resid=None, skip=None, gate=None,
+              gate_sample_stride=0, rows_per_sample=0, step_ptr=None, gate_step_stride=0, n=None):
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T + bias).  x, w bf16 (K % 64 == 0)."""
+    _need(x, torch.bfloat16, "x"); _need(w, torch.bfloat16, "w"); _need(bias, torch.float32, "bias")
+    _rowmajor(x, "x"); _rowmajor(w, "w")
+    M, K = x.shape
+    N = n if n is not None else w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("gemm: K mismatch x%s w%s" % (tuple(x.shape), tuple(w.shape)))
+    if out is None:
+        odt = torch.float32 if epilogue in (EPI_F32, EPI_RESID_F32) else torch.bfloat16
+        out = torch.empty((M, N), dtype=odt, device=x.device)
+    if epilogue == EPI_RESID_F32 and resid is None:
+        resid = out
+    check(lib().ldt_gemm_bf16(epilogue, _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+                              _p(resid), resid.stride(0) if resid is not None else 0,
+                              _p(skip), skip.stride(0) if skip is not None else 0,
+                              _p(gate), gate_sample_stride, rows_per_sample, _p(step_ptr), gate_step_stride,
+                              M, N, K, stream_ptr()), "ldt_gemm_bf16")
+    return out
+
+
+def layernorm_modulate(x, w=None, b=None, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=0,
+                       step_ptr=None, mod_step_stride=0, out=None):
+    """x fp32 [M,C] -> bf16 [M,C]: LN(eps 1e-6)[*w+b] then *(1+scale)+shift (per-sample vectors)."""
+    _need(x, torch.float32, "x")
+    _rowmajor(x, "x")
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib().ldt_layernorm_modulate(_p(x), x.stride(0), _p(out), out.stride(0), _p(w), _p(b), _p(shift), _p(scale),
+                                       mod_sample_stride, rows_per_sample, _p(step_ptr), mod_step_stride, M, Cc,
+                                       stream_ptr()), "ldt_layernorm_modulate")
+    return out
+
+
+def attention_fwd(q, k, v, B, H, Nq, Nk, head_dim, out=None):
+    """q [B*Nq, >=H*Dh] , k/v [B*Nk, ...] bf16 row views (heads at column h*Dh) -> O [B,H,Nq,Dh] bf16."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, torch.bfloat16, nm); _rowmajor(t, nm)
+    if out is None:
+        out = torch.empty((B, H, Nq, head_dim), dtype=torch.bfloat16, device=q.device)
+    if k.stride(0) * Nk != v.stride(0) * Nk:
+        raise ValueError("attention: K and V must share the batch stride")
+    check(lib().ldt_attention_fwd(_p(q), q.stride(0), q.stride(0) * Nq, _p(k), k.stride(0), _p(v), v.stride(0),
+                                  k.stride(0) * Nk, _p(out), B, H, Nq, Nk, head_dim, stream_ptr()), "ldt_attention_fwd")
+    return out
+
+
+def sgemm(a, w, bias=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None, out_bf16=False):
+    """fp32: out[M,N] = act_out(act_in(a[M,K]) @ w[N,K]^T + bias)."""
+    _need(a, torch.float32, "a"); _need(w, torch.float32, "w"); _need(bias, torch.float32, "bias")
+    _rowmajor(a, "a"); _rowmajor(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("sgemm: K mismatch a%s w%s" % (tuple(a.shape), tuple(w.shape)))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    else:
+        out_bf16 = out.dtype == torch.bfloat16
+    check(lib().ldt_sgemm(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), int(out_bf16),
+                          act_in, act_out, M, N, K, stream_ptr()), "ldt_sgemm")
+    return out
+
+
+def sinusoid(t, freq):
+    _need(t, torch.float32, "t"); _need(freq, torch.float32, "freq")
+    e = torch.empty((t.numel(), 2 * freq.numel()), dtype=torch.float32, device=t.device)
+    check(lib().ldt_sinusoid(_p(t), _p(freq), _p(e), t.numel(), freq.numel(), stream_ptr()), "ldt_sinusoid")
+    return e
+
+
+def sampler_step(x, params, coef, step, mode=0, noise=None, noise_step_stride=0, x_out=None, x_mean_out=None,
+                 step_ptr=None, elem_offset=0, seed=0):
+    _need(x, torch.float32, "x"); _need(params, torch.float32, "params"); _need(coef, torch.float32, "coef")
+    _need(noise, torch.float32, "noise")
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    check(lib().ldt_sampler_step(_p(x), _p(params), _p(noise), noise_step_stride, _p(x_out), _p(x_mean_out), _p(coef),
+                                 _p(step_ptr), int(step), mode, x.numel(), elem_offset, seed, stream_ptr()),
+          "ldt_sampler_step")
+    return x_out
+
+
+def philox_normal(shape, device, seed, step=0, elem_offset=0):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib().ldt_philox_normal(_p(out), out.numel(), elem_offset, step, seed, stream_ptr()), "ldt_philox_normal")
+    return out

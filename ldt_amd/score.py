@@ -1,0 +1,177 @@
+"""`Score` — the eps-prediction Transformer (reference: model/scorenet/score.py:47-151), MI355X path.
+
+Same constructor, parameter tree and `forward(x, t, label=None, condition=None)` contract as the
+reference class; the arithmetic is one `ldt_score_forward` call into libldt_hip.so (24 x [LN+AdaLN ->
+QKV GEMM -> fused attention -> out-proj+gate+residual -> LN+AdaLN -> MLP-up+GELU -> MLP-down+gate+residual]).
+
+Host-side responsibilities kept in Python:
+  * weight packing: Conv1d (out,in,1) fp32 -> bf16 [N][K] panels, fc_q|fc_kv concatenated to one
+    [3C][C] operand (self-attention: both read the same modulated input, layers.py:184-189); repacked
+    when the parameters change (EMA swap, tools/utils.py:80-101).
+  * AdaLN tables: c = TimeEmbedding(t) and every block's adaLN Linear(SiLU(c)) (layers.py:172,214,
+    238,244) are evaluated in fp32 for a whole vector of times at once (`time_table`).  In unconditional
+    sampling t is one scalar per step (diffusion_continuous.py:243-244), so the sampler builds the table
+    for all N steps in one batched call instead of 25 GEMVs per step (SURVEY hard part 3).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_NONE, ACT_SILU, MAX_BLOCKS, ScorePlan, check, lib
+from .layers import FinalLayer, LabelEmbedding, ResidualBlock, TimeEmbedding, conv_w, params_fingerprint
+
+
+class Score(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.z_dim = cfg.z_dim
+        self.out_dim = self.z_dim
+        self.z_scale = cfg.z_scale
+        self.hidden_size = cfg.hidden_size
+        self.num_heads = cfg.num_heads
+        self.condition = cfg.condition
+        self.num_steps = cfg.num_steps
+        self.norm = cfg.norm
+        self.t_dim = cfg.t_dim
+        self.num_blocks = cfg.num_blocks
+        self.unet = cfg.unet
+        self.AdaLN = cfg.AdaLN
+        if self.condition:
+            raise NotImplementedError("ViPC ConditionNet (score.py:13-44) is scheduled next (SURVEY §8f)")
+        if self.unet:
+            raise NotImplementedError("unet: True Score variant (score.py:67-83) is not on the shipped path")
+        if not self.AdaLN or getattr(cfg, "dropout", 0.):
+            raise NotImplementedError("only AdaLN blocks without dropout are built")
+        if self.num_blocks > MAX_BLOCKS:
+            raise ValueError("num_blocks > %d" % MAX_BLOCKS)
+        self.Transformer = nn.ModuleList([
+            ResidualBlock(self.hidden_size, self.hidden_size, self.t_dim, self.num_heads, norm=self.norm,
+                          act=cfg.act, AdaLN=self.AdaLN) for _ in range(self.num_blocks)])
+        if cfg.num_categorys > 1:
+            self.LabelEmbedding = LabelEmbedding(cfg.num_categorys, self.t_dim, self.t_dim)
+        else:
+            self.label_dim = None
+        self.ln_in = nn.Conv1d(self.z_dim, self.hidden_size, 1)
+        self.TimeEmbedding = TimeEmbedding(self.t_dim // 4, self.t_dim)
+        self.ln_out = FinalLayer(self.hidden_size, self.z_dim, self.t_dim, self.norm)
+        self._pack = None
+        self._pack_key = None
+        self._ws = {}
+        self._freq = None
+
+    # ------------------------------------------------------------------ packed weights
+    @property
+    def n_mod(self):
+        return self.num_blocks * 6 * self.hidden_size + 2 * self.hidden_size
+
+    def _device(self):
+        return self.ln_in.weight.device
+
+    def packed(self):
+        """bf16 operand panels + fp32 biases, rebuilt when any parameter changed (EMA swap => repack)."""
+        key = params_fingerprint(self)
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("Score parameters are on %s: the HIP path needs them on the GPU (.to('cuda'))" % dev)
+        with torch.no_grad():
+            P = {"w_qkv": [], "b_qkv": [], "w_o": [], "b_o": [], "w_up": [], "b_up": [], "w_dn": [], "b_dn": []}
+            zp = ops.pad64(self.z_dim)
+            P["w_in"] = ops.cast_pad_bf16(conv_w(self.ln_in).float().contiguous(), zp)
+            P["b_in"] = self.ln_in.bias.detach().float().contiguous()
+            for blk in self.Transformer:
+                wqkv = torch.cat([conv_w(blk.fc_q), conv_w(blk.fc_kv)], 0).float().contiguous()
+                P["w_qkv"].append(ops.cast_pad_bf16(wqkv, wqkv.shape[1]))
+                P["b_qkv"].append(torch.cat([blk.fc_q.bias, blk.fc_kv.bias]).detach().float().contiguous())
+                for nm, m in (("o", blk.fc_o), ("up", blk.mlp.fc[0][0]), ("dn", blk.mlp.out)):
+                    w = conv_w(m).float().contiguous()
+                    P["w_" + nm].append(ops.cast_pad_bf16(w, w.shape[1]))
+                    P["b_" + nm].append(m.bias.detach().float().contiguous())
+            w = conv_w(self.ln_out.ln).float().contiguous()
+            P["w_out"] = ops.cast_pad_bf16(w, w.shape[1])
+            P["b_out"] = self.ln_out.ln.bias.detach().float().contiguous()
+        self._pack, self._pack_key = P, key
+        return P
+
+    def _workspace(self, B, T):
+        k = (B, T, self._device())
+        if k not in self._ws:
+            dev, M, D = self._device(), B * T, self.hidden_size
+            bf = dict(dtype=torch.bfloat16, device=dev)
+            self._ws = {k: {
+                "xin": torch.zeros((M, ops.pad64(self.z_dim)), **bf),
+                "X": torch.empty((M, D), dtype=torch.float32, device=dev),
+                "Hb": torch.empty((M, D), **bf), "QKV": torch.empty((M, 3 * D), **bf),
+                "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
+            }}
+        return self._ws[k]
+
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride):
+        """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`."""
+        P, W = self.packed(), self._workspace(B, T)
+        p = ScorePlan()
+        p.hidden, p.heads, p.blocks = self.hidden_size, self.num_heads, self.num_blocks
+        p.z_dim, p.z_pad, p.mlp_hidden = self.z_dim, ops.pad64(self.z_dim), W["U"].shape[1]
+        p.tokens, p.batch = T, B
+        p.w_in, p.b_in = P["w_in"].data_ptr(), P["b_in"].data_ptr()
+        for l in range(self.num_blocks):
+            for nm in ("qkv", "o", "up", "dn"):
+                getattr(p, "w_" + nm)[l] = P["w_" + nm][l].data_ptr()
+                getattr(p, "b_" + nm)[l] = P["b_" + nm][l].data_ptr()
+        p.w_out, p.b_out = P["w_out"].data_ptr(), P["b_out"].data_ptr()
+        p.mod, p.mod_step_stride, p.mod_sample_stride = mod.data_ptr(), mod_step_stride, mod_sample_stride
+        for nm in ("xin", "X", "Hb", "QKV", "Ob", "U"):
+            setattr(p, nm, W[nm].data_ptr())
+        p._keep = (P, W, mod)            # keep the buffers alive as long as the plan
+        return p
+
+    # ------------------------------------------------------------------ AdaLN tables
+    def _frequencies(self):
+        """model/layers.py:29-30 evaluated with the reference's own fp32 ops (quirk Q5), cached on device."""
+        if self._freq is None or self._freq.device != self._device():
+            half = self.TimeEmbedding.t_emb_dim // 2
+            s = np.log(10000) / (half - 1)
+            self._freq = torch.exp(torch.arange(half) * -s).to(self._device())
+        return self._freq
+
+    def time_table(self, t, extra_c=None):
+        """t [n] fp32 on device -> (c [n,t_dim], mod [n,n_mod]) in fp32.
+        c = TimeEmbedding(t) (+ extra_c: label / image-condition embedding, score.py:135);
+        mod[:, l*6D:(l+1)*6D] = adaLN_l(SiLU(c)); the last 2D columns are FinalLayer's (shift, scale)."""
+        te = self.TimeEmbedding.mlp
+        e = ops.sinusoid(t.contiguous(), self._frequencies())
+        h = ops.sgemm(e, te[0].weight, te[0].bias, act_out=ACT_SILU)
+        c = ops.sgemm(h, te[2].weight, te[2].bias)
+        if extra_c is not None:
+            c = c + extra_c
+        D = self.hidden_size
+        mod = torch.empty((t.numel(), self.n_mod), dtype=torch.float32, device=t.device)
+        for l, blk in enumerate(self.Transformer):
+            lin = blk.adaLN[1]
+            ops.sgemm(c, lin.weight, lin.bias, act_in=ACT_SILU, out=mod[:, l * 6 * D:(l + 1) * 6 * D])
+        lin = self.ln_out.adaLN[1]
+        ops.sgemm(c, lin.weight, lin.bias, act_in=ACT_SILU, out=mod[:, self.num_blocks * 6 * D:])
+        return c, mod
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward(self, x, t, label=None, condition=None):
+        """x (bs, tokens, z_dim), t (bs,) -> predicted noise (bs, tokens, z_dim)   [score.py:117-151]"""
+        if label is not None or condition is not None:
+            raise NotImplementedError("label / ViPC conditioning is scheduled next (SURVEY §8f)")
+        if not x.is_cuda:
+            raise RuntimeError("Score.forward: x is on %s; the HIP path has no CPU fallback" % x.device)
+        B, T, z = x.shape
+        assert z == self.z_dim
+        x = x.contiguous().float()
+        _, mod = self.time_table(t.to(x).float())
+        plan = self.plan(B, T, mod, 0, self.n_mod)            # per-sample AdaLN rows
+        out = torch.empty_like(x)
+        check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), None, ops.stream_ptr()),
+              "ldt_score_forward")
+        return out

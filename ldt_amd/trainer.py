@@ -1,0 +1,154 @@
+"""`Trainer` — sampling half of the reference trainer (trainer/Latent_SDE_Trainer.py), MI355X path.
+
+Kept: `Trainer(cfg, model, compressor, device)`, `score_fn(t, x, label, condition) -> (score, params)` (:57-61),
+`sample(num_samples, num_points, label, condition) -> (points, eps)` (:143-165), `valsample`-style "Sample rate"
+timing (:178-181,206), EMA weight swap (:146,164; tools/utils.py:80-101) and the checkpoint keys (:232-235,
+:251-256).  Training (`update*`, optimizers, schedulers) is out of scope for this path.
+
+Multi-GPU: when torch.distributed is initialised, `sample(B)` runs rows [lo,hi) of the batch on this rank and
+all-gathers the finished points/latents once (ldt_amd/dist.py); results do not depend on the world size when
+every rank seeds the CPU generator identically (the reference's common_init, tools/utils.py:269-276).
+"""
+import time
+
+import torch
+
+from . import dist as ldist
+from .diffusion import DiffusionVPSDE
+
+
+class EMAWeights:
+    """The part of tools/utils.py:25-101 (EMA optimizer wrapper) the sampler touches: `state[p]['ema']` and
+    `swap_parameters_with_ema`.  With no EMA state (fresh model) the swap is a no-op, as upstream (:93-94)."""
+
+    def __init__(self, params, ema_decay):
+        self.ema_decay = ema_decay
+        self.apply_ema = ema_decay > 0.
+        self.params = list(params)
+        self.state = {}
+
+    def load_ema(self, optim_state_dict):
+        """Adopt the 'ema' tensors of a reference optimizer state_dict (`score_optim_state_dict`,
+        Latent_SDE_Trainer.py:233): its param ids follow parameter order."""
+        st = optim_state_dict.get("state", {})
+        for i, p in enumerate(self.params):
+            if i in st and "ema" in st[i]:
+                self.state[p] = {"ema": st[i]["ema"].to(p.device, p.dtype)}
+
+    def swap_parameters_with_ema(self, store_params_in_ema):
+        if not self.apply_ema:
+            return
+        for p in self.params:
+            if not p.requires_grad or p not in self.state or "ema" not in self.state[p]:
+                continue
+            ema = self.state[p]["ema"]
+            if store_params_in_ema:
+                tmp = p.data.detach()
+                p.data = ema.detach()
+                self.state[p]["ema"] = tmp
+            else:
+                p.data = ema.detach()
+
+
+class Trainer:
+    def __init__(self, cfg, model, compressor, device):
+        self.cfg = cfg
+        if cfg.sde.sde_type != "vpsde":
+            raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % cfg.sde.sde_type)
+        self.SDE = DiffusionVPSDE(cfg.sde)
+        self.sde_type = cfg.sde.sde_type
+        self.num_points = cfg.data.tr_max_sample_points
+        self.device = device
+        self.num_categorys = cfg.data.num_categorys
+        self.model = model.to(device)
+        self.compressor = compressor.to(device)
+        self.optimizer = EMAWeights(self.model.parameters(), ema_decay=cfg.opt.ema_decay)
+        self.sample_time_eps = cfg.sde.sample_time_eps
+        self.sample_N = cfg.sde.sample_N
+        self.sample_mode = cfg.sde.sample_mode
+        self.epoch, self.itr = 1, 0
+
+    def score_fn(self, t, x, label=None, condition=None):
+        t = t.to(x)
+        params = self.model(x, t, label=label, condition=condition)
+        var = self.SDE.var(t)[:, None, None]
+        return -params / torch.sqrt(var), params
+
+    @torch.no_grad()
+    def sample(self, num_samples, num_points=None, label=None, condition=None, *, x0=None, noise=None, seed=None,
+               use_graph=None):
+        self.model.eval()
+        self.compressor.eval()
+        self.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
+        try:
+            if self.sample_mode != "discrete":
+                raise NotImplementedError("sample_mode 'continuous' (ODE, needs torchdiffeq) is out of scope; "
+                                          "the shipped config uses 'discrete'")
+            cs = self.cfg.score
+            shape = (cs.z_scale, cs.z_dim + 3 if getattr(cs, "graphconv", False) else cs.z_dim)
+            rank, ws = ldist.world()
+            lo, hi, per = ldist.shard_bounds(num_samples, rank, ws)
+            # every rank draws the FULL-batch x0 from its (identically seeded) CPU generator, then keeps its rows
+            if x0 is None:
+                x0 = torch.randn((num_samples,) + shape)
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            x0_loc = _rows(x0, lo, hi, per)
+            noise_loc = None if noise is None else _rows(noise.transpose(0, 1), lo, hi, per).transpose(0, 1)
+            eps = self.SDE.sample_discrete(score_fn=self.score_fn, N=self.cfg.sde.sample_N,
+                                           corrector=self.cfg.sde.corrector, predictor=self.cfg.sde.predictor,
+                                           corrector_steps=self.cfg.sde.corrector_steps, shape=shape,
+                                           time_eps=self.sample_time_eps, label=label, denoise=self.cfg.sde.denoise,
+                                           device=self.device, num_samples=per,
+                                           probability_flow=self.cfg.sde.probability_flow, snr=self.cfg.sde.snr,
+                                           condition=condition, x0=x0_loc, noise=noise_loc, sample_offset=lo,
+                                           seed=seed, use_graph=use_graph)
+            npts = self.num_points if num_points is None else num_points
+            sample = self.compressor.sample((per, npts), given_eps=eps)
+            if ws > 1:                                   # the single collective of the path
+                sample = ldist.all_gather_rows(sample, num_samples)
+                eps = ldist.all_gather_rows(eps, num_samples)
+        finally:
+            self.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
+        return sample, eps
+
+    @torch.no_grad()
+    def valsample(self, batches, batch_size=None):
+        """Timing loop of valsample (:167-206): returns (all samples, shapes/second) and prints "Sample rate"."""
+        batch_size = batch_size or self.cfg.data.test_batch_size
+        out, use_time = [], 0.
+        for _ in range(batches):
+            torch.cuda.synchronize()
+            T0 = time.time()
+            smp, _ = self.sample(num_samples=batch_size)
+            torch.cuda.synchronize()
+            use_time += time.time() - T0
+            out.append(smp)
+        smp = torch.cat(out, 0)
+        rate = smp.shape[0] / use_time
+        print("Sample rate: %.8f " % rate)
+        return smp, rate
+
+    # ---- checkpoints: the reference's dict layout (:228-266) ------------------------------------------
+    def resume(self, path, strict=True):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ckpt["score_state_dict"], strict=strict)
+        self.compressor.load_state_dict(ckpt["compressor_state_dict"], strict=strict)
+        if "score_optim_state_dict" in ckpt:
+            self.optimizer.load_ema(ckpt["score_optim_state_dict"])
+        self.compressor.init()
+        self.epoch, self.itr = ckpt.get("epoch", 1), ckpt.get("itr", 0)
+
+    def load_pretrain(self, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        self.compressor.load_state_dict(ckpt["state_dict"], strict=True)
+        self.compressor.init()
+
+
+def _rows(t, lo, hi, per):
+    """Rows [lo,hi) of a full-batch tensor, zero-padded to `per` rows (last rank when B % world != 0)."""
+    part = t[lo:min(hi, t.shape[0])]
+    if part.shape[0] < per:
+        pad = torch.zeros((per - part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+        part = torch.cat([part, pad], 0)
+    return part

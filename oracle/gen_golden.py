@@ -63,9 +63,11 @@ class Recorder:
 
 def tiny_cfg(N=50):
     cfg = R.load_airplane_cfg(**{
-        "score.z_scale": 8, "score.hidden_size": 32, "score.num_heads": 4, "score.num_blocks": 2,
-        "score.t_dim": 32,
-        "compressor.z_scales": 8, "compressor.hidden_dim": 32, "compressor.p_dim": 32,
+        # sizes the MFMA kernels accept (channels % 64 == 0, head dim 64 / 32 like the shipped config)
+        "score.z_scale": 8, "score.hidden_size": 128, "score.num_heads": 2, "score.num_blocks": 2,
+        "score.t_dim": 64,
+        "compressor.z_scales": 8, "compressor.hidden_dim": 64, "compressor.num_heads": 2, "compressor.p_dim": 32,
+        "compressor.n_layers": 3, "compressor.z_dim": 40,
         "compressor.max_outputs": 64, "compressor.outsize": 64, "sde.sample_N": N})
     cfg.data.tr_max_sample_points = 64
     return cfg
@@ -110,7 +112,7 @@ def main():
 
     # ---- a9-a12 / Q1-Q4: ResidualBlock variants ---------------------------------------
     torch.manual_seed(11)
-    C, H, N, M, PD = 64, 4, 8, 16, 24
+    C, H, N, M, PD = 64, 2, 8, 16, 24
     g = torch.Generator().manual_seed(5)
     # (i) Score-style: AdaLN, y=None (K/V from modulated x)
     blk = ResidualBlock(C, C, PD, H, norm="layer_norm").eval()

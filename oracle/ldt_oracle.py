@@ -196,18 +196,19 @@ def score_fn_from_model(sde, model_fn):
 
 
 def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_eps=1e-6,
-                    denoise=True, probability_flow=False, record=None):
+                    denoise=True, probability_flow=False, record=None, max_steps=None):
     """diffusion/diffusion_continuous.py:133-258,318-338 (pc_sampling, corrector=None).
 
     x0 [B,T,z] is the initial N(0,1) draw (:237), noises[i] the step-i draw of
     randn_like(x) (:160 etc.; the last one is drawn but unused when denoise, quirk Q8).
-    record: optional list that receives (x_in, params, x_mean, x_out) per step."""
+    record: optional list that receives (x_in, params, x_mean, x_out) per step.
+    max_steps: stop after that many steps (bench.py's bounded CPU-baseline sample)."""
     T = 1.0
     B = x0.shape[0]
     x = x0
     timesteps = torch.linspace(T, time_eps, N)                      # :238
     x_mean = x
-    for i in range(N):
+    for i in range(N if max_steps is None else min(N, max_steps)):
         t = torch.ones((B,)) * timesteps[i]                         # :243-244
         z = noises[i]
         if predictor == "ancestral":                                # :152-162

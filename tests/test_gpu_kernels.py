@@ -1,0 +1,228 @@
+"""GPU (-m gpu): each HIP kernel through the C-ABI vs the CPU oracle / an fp32 torch-CPU restatement.
+
+Tolerances.  Inputs to the MFMA kernels are bf16-rounded FIRST, so GEMM / attention differ from the fp32
+reference only by accumulation order and the bf16 rounding of the output: rel-MSE <= 1e-5 (bf16 out:
+(2^-9)^2/3 ~ 1.3e-6) and <= 1e-9 for fp32 outputs.  fp32 kernels (sgemm, LN statistics, sampler update) are
+held to fp32 round-off; the ancestral update is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_mse
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+O = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _mods():
+    global ops, O
+    assert torch.cuda.is_available()
+    from ldt_amd import ops as _ops
+    from oracle import ldt_oracle as _O
+    ops, O = _ops, _O
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def dev(x, dt=None):
+    return x.to("cuda", dt) if dt else x.to("cuda")
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (16, 120, 1024), (1000, 3072, 1024),
+                                   (77, 64, 192), (2048, 1024, 4096), (130, 132, 64)])
+def test_gemm_all_epilogues(M, N, K):
+    from ldt_amd._lib import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + bias.double()
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(bias)
+    out = ops.gemm_bf16(xd, wd, bd, EPI_F32)
+    assert rel_mse(out.cpu(), ref) < 1e-9
+    out = ops.gemm_bf16(xd, wd, bd, EPI_BF16)
+    assert rel_mse(out.float().cpu(), ref) < 1e-5
+    out = ops.gemm_bf16(xd, wd, bd, EPI_GELU_BF16)
+    assert rel_mse(out.float().cpu(), torch.nn.functional.gelu(ref)) < 1e-5
+    skip = bf(torch.randn(M, N, generator=g))
+    out = ops.gemm_bf16(xd, wd, bd, EPI_RELU_BF16, skip=dev(skip, torch.bfloat16))
+    assert rel_mse(out.float().cpu(), torch.relu(ref + skip.double())) < 1e-5
+    out = ops.gemm_bf16(xd, wd, bd, EPI_RELU_BF16)
+    assert rel_mse(out.float().cpu(), torch.relu(ref)) < 1e-5
+    # residual + per-sample gate (rows_per_sample = 8 if it divides M)
+    rps = 8 if M % 8 == 0 else M
+    S = M // rps
+    resid = torch.randn(M, N, generator=g); gate = torch.randn(S, 3 * N, generator=g)
+    rd = dev(resid.clone())
+    ops.gemm_bf16(xd, wd, bd, EPI_RESID_F32, out=rd, resid=rd, gate=dev(gate)[:, N:2 * N], gate_sample_stride=3 * N,
+                  rows_per_sample=rps)
+    gref = resid.double() + gate[:, N:2 * N].double().repeat_interleave(rps, 0) * ref
+    assert rel_mse(rd.cpu(), gref) < 1e-9
+    rd = dev(resid.clone())
+    ops.gemm_bf16(xd, wd, bd, EPI_RESID_F32, out=rd, resid=rd)
+    assert rel_mse(rd.cpu(), resid.double() + ref) < 1e-9
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an ASYMMETRIC B catches a transposed C write (guide §3)."""
+    from ldt_amd._lib import EPI_F32
+    K = N = 128
+    x = torch.eye(128, K)
+    w = bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 100)
+    out = ops.gemm_bf16(dev(x, torch.bfloat16), dev(w, torch.bfloat16), None, EPI_F32)
+    assert torch.equal(out.cpu(), w.T.contiguous())
+
+
+def test_gemm_rejects_bad_shapes():
+    from ldt_amd._lib import LdtHipError
+    x = torch.zeros(8, 72, dtype=torch.bfloat16, device="cuda"); w = torch.zeros(8, 72, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(LdtHipError):
+        ops.gemm_bf16(x, w)
+    with pytest.raises(LdtHipError):
+        ops.gemm_bf16(x.cpu(), w.cpu())
+
+
+# ------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, H):
+    """oracle/ldt_oracle.attention minus the projections: -> [B,H,N,Dh] contiguous."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    dh = C // H
+    sp = lambda z, n: z.reshape(B, n, H, dh).permute(0, 2, 1, 3).double()
+    w = (sp(q, N) @ sp(k, M).transpose(-1, -2) * dh ** -0.5).softmax(-1)
+    return (w @ sp(v, M)).contiguous()
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,dh", [(2, 16, 256, 256, 64), (3, 4, 32, 32, 64), (2, 2, 8, 8, 64), (2, 4, 300, 77, 32),
+                                         (1, 4, 2048, 256, 32), (2, 4, 40, 2048, 32), (1, 2, 130, 512, 64), (2, 2, 8, 5, 32)])
+def test_attention(B, H, Nq, Nk, dh):
+    g = torch.Generator().manual_seed(Nq + Nk)
+    C = H * dh
+    q = bf(torch.randn(B, Nq, C, generator=g)); kv = bf(torch.randn(B, Nk, 2 * C, generator=g) * 1.5)
+    ref = ref_attention(q, kv[..., :C], kv[..., C:], H)
+    qd = dev(q, torch.bfloat16).view(B * Nq, C); kvd = dev(kv, torch.bfloat16).view(B * Nk, 2 * C)
+    out = ops.attention_fwd(qd, kvd[:, :C], kvd[:, C:], B, H, Nq, Nk, dh)
+    assert out.shape == (B, H, Nq, dh)
+    assert rel_mse(out.float().cpu(), ref) < 2e-5
+    assert float((out.float().cpu() - ref).abs().max()) < 0.05
+
+
+def test_attention_softmax_spike():
+    """A key row that dominates one query row late in the sequence forces the online-softmax rescale."""
+    B, H, N, dh = 1, 1, 256, 64
+    q = torch.zeros(B, N, dh); k = torch.zeros(B, N, dh); v = torch.randn(B, N, dh, generator=torch.Generator().manual_seed(3))
+    q[0, 5, 0] = 8.0; k[0, 200, 0] = 16.0          # score 128/8 = 16 at key 200 only for query 5
+    q, k, v = bf(q), bf(k), bf(v)
+    ref = ref_attention(q, k, v, H)
+    out = ops.attention_fwd(dev(q, torch.bfloat16).view(N, dh), dev(k, torch.bfloat16).view(N, dh),
+                            dev(v, torch.bfloat16).view(N, dh), B, H, N, N, dh)
+    assert float((out.float().cpu() - ref).abs().max()) < 0.02
+
+
+# ------------------------------------------------------------------------------------------- LN / modulate
+@pytest.mark.parametrize("M,C", [(64, 1024), (10, 128), (33, 64), (8, 256), (5, 96)])
+def test_layernorm_modulate(M, C):
+    g = torch.Generator().manual_seed(C)
+    rps = 1 if M % 2 else 2
+    S = M // rps
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    mod = torch.randn(S, 2 * C, generator=g) * 0.5
+    w = torch.rand(C, generator=g) + 0.5; b = torch.randn(C, generator=g)
+    md = dev(mod)
+    out = ops.layernorm_modulate(dev(x), shift=md[:, :C], scale=md[:, C:], mod_sample_stride=2 * C, rows_per_sample=rps)
+    ref = O.modulate(O.layer_norm(x.double()), mod[:, :C].double().repeat_interleave(rps, 0), mod[:, C:].double().repeat_interleave(rps, 0))
+    assert rel_mse(out.float().cpu(), ref) < 1e-5
+    out = ops.layernorm_modulate(dev(x), w=dev(w), b=dev(b))
+    assert rel_mse(out.float().cpu(), O.layer_norm(x.double(), w.double(), b.double())) < 1e-5
+    out = ops.layernorm_modulate(dev(x))
+    assert rel_mse(out.float().cpu(), O.layer_norm(x.double())) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- fp32 linears
+@pytest.mark.parametrize("M,N,K", [(5, 64, 3), (300, 128, 20), (1000, 768, 64), (7, 2048, 1024), (65, 40, 128)])
+def test_sgemm(M, N, K):
+    from ldt_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU
+    g = torch.Generator().manual_seed(K)
+    a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    F = torch.nn.functional
+    out = ops.sgemm(dev(a), dev(w), dev(b))
+    assert rel_mse(out.cpu(), a.double() @ w.double().T + b.double()) < 1e-12
+    out = ops.sgemm(dev(a), dev(w), dev(b), act_in=ACT_SILU, act_out=ACT_RELU)
+    assert rel_mse(out.cpu(), torch.relu(F.silu(a.double()) @ w.double().T + b.double())) < 1e-12
+    out = ops.sgemm(dev(a), dev(w), None, act_out=ACT_GELU, out_bf16=True)
+    assert rel_mse(out.float().cpu(), F.gelu(a.double() @ w.double().T)) < 1e-5
+    # strided input / output views
+    big = torch.randn(M, K + 11, generator=g)
+    outb = torch.zeros(M, N + 5, device="cuda")
+    ops.sgemm(dev(big)[:, 3:3 + K], dev(w), dev(b), out=outb[:, 2:2 + N])
+    assert rel_mse(outb[:, 2:2 + N].cpu(), big[:, 3:3 + K].double() @ w.double().T + b.double()) < 1e-12
+    assert float(outb[:, :2].abs().sum()) == 0
+
+
+def test_time_embedding_golden():
+    """sinusoid + TimeEmbedding.mlp on device vs the golden captured from the reference (a8, Q5)."""
+    from conftest import load_golden
+    from ldt_amd._lib import ACT_SILU
+    a, sds = load_golden("time_embedding")
+    half = 128
+    freq = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1)))
+    e = ops.sinusoid(dev(a["t"]), dev(freq))
+    assert float((e.cpu() - a["sinusoid"]).abs().max()) < 2e-6
+    w = sds["w"]
+    h = ops.sgemm(e, dev(w["mlp.0.weight"]), dev(w["mlp.0.bias"]), act_out=ACT_SILU)
+    out = ops.sgemm(h, dev(w["mlp.2.weight"]), dev(w["mlp.2.bias"]))
+    assert rel_mse(out.cpu(), a["out"]) < 1e-10
+
+
+# ------------------------------------------------------------------------------------------- sampler update
+def test_sampler_step_ancestral_bit_exact(tiny_cfg):
+    from ldt_amd.diffusion import DiffusionVPSDE
+    N = 1000
+    tiny_cfg.sde.sample_N = N
+    sde = DiffusionVPSDE(tiny_cfg.sde)
+    osde = O.VPSDE(tiny_cfg.sde)
+    tiny_cfg.sde.sample_N = 50
+    ts, coef, mode = sde.step_table(N, "ancestral", 1e-6)
+    assert mode == 0
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 8, 120, generator=g) * 5; p = torch.randn(2, 8, 120, generator=g); z = torch.randn(2, 8, 120, generator=g)
+    for i in (0, 1, 500, 998, 999):
+        t = torch.ones(2) * ts[i]
+        idx = (t * (N - 1)).long(); beta = osde.betas[idx]
+        score = -p / torch.sqrt(osde.var(t))[:, None, None]
+        xm = (x + beta[:, None, None] * score) / torch.sqrt(1. - beta)[:, None, None]
+        xn = xm + torch.sqrt(beta)[:, None, None] * z
+        xmd = torch.empty_like(x, device="cuda")
+        out = ops.sampler_step(dev(x), dev(p), dev(coef), i, 0, noise=dev(z), x_mean_out=xmd)
+        assert torch.equal(xmd.cpu(), xm), i
+        assert torch.equal(out.cpu(), xn), i
+
+
+def test_sampler_step_device_counter_and_noise_stride():
+    coef = torch.tensor([[1.5, -0.5, 2.0, 0.0], [0.5, 0.25, 1.0, 0.0]])
+    x = torch.randn(64); p = torch.randn(64); nz = torch.randn(2, 64)
+    ctr = torch.tensor([1], dtype=torch.int32, device="cuda")
+    out = ops.sampler_step(dev(x), dev(p), dev(coef), 0, 1, noise=dev(nz), noise_step_stride=64, step_ptr=ctr)
+    assert torch.allclose(out.cpu(), 0.5 * x + 0.25 * p + nz[1], atol=1e-6)
+
+
+def test_philox_normal_statistics_and_shard_invariance():
+    n = 1 << 20
+    a = ops.philox_normal((n,), "cuda", seed=1234, step=7)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 3).mean())) < 2e-2 and abs(float((a ** 4).mean()) - 3) < 5e-2
+    lo = ops.philox_normal((n // 2,), "cuda", seed=1234, step=7)
+    hi = ops.philox_normal((n // 2,), "cuda", seed=1234, step=7, elem_offset=n // 2)
+    assert torch.equal(torch.cat([lo, hi]), a)                      # sharding by element offset is invisible
+    b = ops.philox_normal((n,), "cuda", seed=1234, step=8)
+    assert abs(float((a * b).mean())) < 5e-3                        # steps are independent streams
+    # the fused step draws the same stream
+    x = torch.zeros(n, device="cuda"); coef = torch.tensor([[1.0, 0.0, 1.0, 0.0]] * 8, device="cuda")
+    out = ops.sampler_step(x, x, coef, 7, 1, seed=1234)
+    assert torch.equal(out, a)

@@ -1,0 +1,177 @@
+"""GPU (-m gpu): the drop-in classes (Score, DiffusionVPSDE, Compressor, Trainer) through the C-ABI vs
+(a) golden vectors captured from the reference and (b) the CPU oracle on seeded inputs.
+
+Stated bf16 tolerances (north-star: per-step MSE + final Chamfer):
+  * teacher-forced Score output `params`, relative MSE ||a-b||^2/||b||^2      <= 1e-4
+  * free-running latents after N steps with injected noise, relative MSE     <= 2e-3
+  * decoded cloud: relative MSE <= 2e-3 and Chamfer(gpu, cpu) / mean squared radius <= 2e-3
+The fp32 pieces (AdaLN tables, sampler update) are held to fp32 round-off in test_gpu_kernels.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_mse
+
+pytestmark = pytest.mark.gpu
+
+TOL_PARAMS, TOL_LATENT, TOL_POINTS, TOL_CD = 1e-4, 2e-3, 2e-3, 2e-3
+
+
+@pytest.fixture(scope="module")
+def env(tiny_cfg):
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    assert torch.cuda.is_available()
+    _, ssd = load_golden("score_tiny")
+    tg, csd = load_golden("trainer_sample_tiny")
+    score = ldt_amd.Score(tiny_cfg.score)
+    score.load_state_dict(ssd["w"], strict=True)            # reference names/shapes load verbatim
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    comp.load_state_dict(csd["c"], strict=True)
+    tr = ldt_amd.Trainer(tiny_cfg, score, comp, "cuda:0")
+    return dict(ldt=ldt_amd, O=O, score=score, comp=comp, tr=tr, ssd=ssd["w"], csd=csd["c"], tg=tg, cfg=tiny_cfg)
+
+
+def test_score_forward_golden(env):
+    a, _ = load_golden("score_tiny")
+    out = env["score"](a["x"].cuda(), a["t"].cuda())
+    assert rel_mse(out.cpu(), a["out"]) < TOL_PARAMS
+
+
+def test_time_table_matches_oracle(env):
+    """c and every AdaLN row in fp32: the batch-shared table == per-sample evaluation."""
+    O, score, cfg = env["O"], env["score"], env["cfg"]
+    t = torch.tensor([1.0, 0.37, 1e-6])
+    c, mod = score.time_table(t.cuda())
+    c_ref = O.time_embedding(env["ssd"], "TimeEmbedding", t, cfg.score.t_dim // 4)
+    assert rel_mse(c.cpu(), c_ref) < 1e-10
+    D = cfg.score.hidden_size
+    for l in range(cfg.score.num_blocks):
+        ref = O.linear(env["ssd"], "Transformer.%d.adaLN.1" % l, torch.nn.functional.silu(c_ref))
+        assert rel_mse(mod[:, l * 6 * D:(l + 1) * 6 * D].cpu(), ref) < 1e-10
+    ref = O.linear(env["ssd"], "ln_out.adaLN.1", torch.nn.functional.silu(c_ref))
+    assert rel_mse(mod[:, -2 * D:].cpu(), ref) < 1e-10
+
+
+def test_teacher_forced_steps_golden(env):
+    """Feed the reference's own x_i / t_i (captured trajectory) and compare params — per-step parity."""
+    tg = env["tg"]
+    worst = 0.0
+    for j in range(tg["step_x"].shape[0]):
+        p = env["score"](tg["step_x"][j].cuda(), tg["step_t"][j].cuda())
+        worst = max(worst, rel_mse(p.cpu(), tg["step_params"][j]))
+    assert worst < TOL_PARAMS, worst
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_trainer_sample_golden(env, use_graph):
+    """Trainer.sample end-to-end with the reference's recorded draws injected: latents, points, Chamfer."""
+    O, tg, tr = env["O"], env["tg"], env["tr"]
+    pts, eps = tr.sample(2, x0=tg["x0"], noise=tg["noises"], use_graph=use_graph)
+    assert pts.shape == tg["points"].shape and eps.shape == tg["eps"].shape
+    assert rel_mse(eps.cpu(), tg["eps"]) < TOL_LATENT
+    assert rel_mse(pts.cpu(), tg["points"]) < TOL_POINTS
+    cd = O.chamfer_cd(pts.cpu(), tg["points"])
+    radius2 = (tg["points"] ** 2).sum(-1).mean(1)
+    assert float((cd / radius2).max()) < TOL_CD
+
+
+def test_free_running_per_step_curve(env):
+    """Generic (Python-driven) loop with record: per-step relative MSE of x against the reference trajectory."""
+    tg, tr, cfg = env["tg"], env["tr"], env["cfg"]
+    rec = []
+    tr.SDE.sample_discrete(score_fn=tr.score_fn, num_samples=2, N=cfg.sde.sample_N, predictor="ancestral", corrector=None,
+                           corrector_steps=1, shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps,
+                           probability_flow=False, denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"],
+                           record=rec)
+    errs = [rel_mse(rec[i][0].cpu(), tg["step_x"][j]) for j, i in enumerate(tg["step_ids"].tolist())]
+    assert max(errs) < TOL_LATENT, errs
+    assert rel_mse(rec[-1][0].cpu(), tg["last_x"]) < TOL_LATENT
+
+
+def test_fused_loop_equals_generic_loop_and_graph(env):
+    tg, tr, cfg = env["tg"], env["tr"], env["cfg"]
+    kw = dict(score_fn=tr.score_fn, num_samples=2, N=cfg.sde.sample_N, predictor="ancestral", corrector=None,
+              corrector_steps=1, shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps,
+              probability_flow=False, denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"])
+    a = tr.SDE.sample_discrete(**kw, use_graph=0)
+    b = tr.SDE.sample_discrete(**kw, use_graph=1)
+    assert torch.equal(a, b)                                  # graph replay == eager launches, bit for bit
+    c = tr.SDE.sample_discrete(**kw, record=[])               # python-driven loop, per-sample AdaLN path
+    assert rel_mse(c.cpu(), a.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("pred", ["reversediffusion", "eulermaruyama", "ddim"])
+def test_other_predictors_golden(env, pred):
+    a, _ = load_golden("other_predictors")
+    tg, tr, cfg = env["tg"], env["tr"], env["cfg"]
+    out = tr.SDE.sample_discrete(score_fn=tr.score_fn, num_samples=2, N=cfg.sde.sample_N, predictor=pred, corrector=None,
+                                 corrector_steps=1, shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps,
+                                 probability_flow=False, denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"])
+    assert rel_mse(out.cpu(), a[pred]) < TOL_LATENT
+
+
+def test_decoder_golden(env):
+    a, _ = load_golden("decoder_tiny")
+    pts = env["comp"].sample((2, 64), given_eps=a["given_eps"].cuda())
+    assert rel_mse(pts.cpu(), a["points"]) < 1e-4
+    pts2 = env["comp"].decode(a["given_eps"].cuda(), 64)
+    assert torch.equal(pts, pts2)
+
+
+def test_philox_sampling_is_seeded_and_shard_invariant(env):
+    """Device-noise mode: same seed -> same shapes; a batch of 4 == two shards of 2 with sample_offset."""
+    tr, cfg = env["tr"], env["cfg"]
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4, cfg.score.z_scale, cfg.score.z_dim, generator=g)
+    kw = dict(score_fn=tr.score_fn, N=cfg.sde.sample_N, predictor="ancestral", corrector=None, corrector_steps=1,
+              shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=False,
+              denoise=True, snr=0.01, device="cuda:0", seed=99)
+    full = tr.SDE.sample_discrete(num_samples=4, x0=x0, **kw)
+    again = tr.SDE.sample_discrete(num_samples=4, x0=x0, **kw)
+    assert torch.equal(full, again)
+    lo = tr.SDE.sample_discrete(num_samples=2, x0=x0[:2], sample_offset=0, **kw)
+    hi = tr.SDE.sample_discrete(num_samples=2, x0=x0[2:], sample_offset=2, **kw)
+    assert rel_mse(torch.cat([lo, hi]).cpu(), full.cpu()) < 1e-6
+    assert torch.isfinite(full).all()
+
+
+def test_midsize_score_vs_oracle():
+    """Seeded random weights at a size the oracle finishes in seconds: B=4, T=64, hidden 256 (Dh 64), 4 blocks."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    cfg = ldt_amd.airplane_config(latent_tokens=64, **{"score.hidden_size": 256, "score.num_heads": 4,
+                                                       "score.num_blocks": 4, "score.t_dim": 128})
+    torch.manual_seed(3)
+    score = ldt_amd.Score(cfg.score)
+    sd = {k: v.detach().clone() for k, v in score.state_dict().items()}
+    score = score.cuda()
+    x = torch.randn(4, 64, 120); t = torch.tensor([1.0, 0.6, 0.2, 1e-6])
+    out = score(x.cuda(), t.cuda())
+    ref = O.score_forward(sd, cfg.score, x, t)
+    assert rel_mse(out.cpu(), ref) < TOL_PARAMS
+
+
+def test_ema_swap_repacks_weights(env):
+    """EMA swap (tools/utils.py:80-101) re-points parameters; the packed bf16 panels must follow."""
+    ldt, cfg = env["ldt"], env["cfg"]
+    score = ldt.Score(cfg.score)
+    score.load_state_dict(env["ssd"])
+    score = score.cuda()
+    a, _ = load_golden("score_tiny")
+    x, t = a["x"].cuda(), a["t"].cuda()
+    base = score(x, t)
+    ema = ldt.EMAWeights(score.parameters(), 0.999)
+    for p in score.parameters():
+        ema.state[p] = {"ema": torch.zeros_like(p.data)}
+    ema.swap_parameters_with_ema(True)
+    zeroed = score(x, t)
+    assert float(zeroed.abs().max()) == 0.0                     # all-zero EMA weights => zero output
+    ema.swap_parameters_with_ema(True)
+    assert torch.equal(score(x, t), base)
+
+
+def test_no_cpu_fallback(env):
+    a, _ = load_golden("score_tiny")
+    with pytest.raises(RuntimeError):
+        env["score"](a["x"], a["t"])

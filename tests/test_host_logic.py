@@ -1,0 +1,170 @@
+"""CPU: host-side logic of the drop-in classes (no kernel launches)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_mse
+
+
+def test_state_dict_names_and_shapes_match_reference(tiny_cfg):
+    import ldt_amd
+    _, ssd = load_golden("score_tiny")
+    _, csd = load_golden("trainer_sample_tiny")
+    score = ldt_amd.Score(tiny_cfg.score)
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    for mod, ref in ((score, ssd["w"]), (comp, csd["c"])):
+        mine = mod.state_dict()
+        assert sorted(mine) == sorted(ref)
+        for k in ref:
+            assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+        mod.load_state_dict(ref, strict=True)
+
+
+def test_full_size_parameter_count():
+    import ldt_amd
+    cfg = ldt_amd.airplane_config()
+    with torch.device("meta"):
+        s = ldt_amd.Score(cfg.score)
+    assert sum(p.numel() for p in s.parameters()) == 457012344       # train_Latent_Diffusion.py:20-21
+
+
+def test_vpsde_tables_and_step_table(tiny_cfg):
+    import ldt_amd
+    for N in (100, 1000):
+        a, _ = load_golden("vpsde_tables_N%d" % N)
+        tiny_cfg.sde.sample_N = N
+        sde = ldt_amd.DiffusionVPSDE(tiny_cfg.sde)
+        assert torch.equal(sde.betas, a["betas"]) and torch.equal(sde.alphas_cump, a["alphas_cump"])
+        ts, coef, mode = sde.step_table(N, "ancestral", tiny_cfg.sde.sample_time_eps)
+        assert mode == 0 and torch.equal(ts, a["timesteps"])
+        assert torch.equal(coef[:, 0], a["betas"][a["idx"]])
+        assert torch.equal(coef[:, 1], a["std"])
+        assert torch.equal(coef[:, 2], torch.sqrt(1. - a["betas"][a["idx"]]))
+        for name in ("var", "std", "g2", "f", "e2int_f"):
+            assert torch.equal(getattr(sde, name)(ts), a[name])
+        assert torch.isfinite(coef).all() and float(coef[-1, 1]) > 0      # std(1e-6) = sqrt(1 ulp), not 0
+    tiny_cfg.sde.sample_N = 50
+    with pytest.raises(NotImplementedError):
+        sde.step_table(10, "bogus", 1e-6)
+
+
+def test_folded_predictor_coefficients_match_oracle_math(tiny_cfg):
+    """x_mean = A x + B params, x = x_mean + C z reproduces the oracle's (reference's) update for one step."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    N = 50
+    sde = ldt_amd.DiffusionVPSDE(tiny_cfg.sde)
+    osde = O.VPSDE(tiny_cfg.sde)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, generator=g); p = torch.randn(2, 4, 8, generator=g); z = torch.randn(2, 4, 8, generator=g)
+    for pred in ("reversediffusion", "eulermaruyama", "ddim"):
+        ts, coef, mode = sde.step_table(N, pred, 1e-6)
+        assert mode == 1
+        for i in (0, 17, N - 1):
+            rec = []
+            fn = lambda t, xx: (-p / torch.sqrt(osde.var(t))[:, None, None], p)
+            # run the oracle for exactly step i by slicing its loop: emulate with N-step call and record
+            O.sample_discrete(osde, fn, x, [z] * N, N, predictor=pred, record=rec)
+            # step 0 record uses x as input; for i>0 inputs differ, so recompute directly for step i:
+            t = torch.ones(2) * ts[i]
+            one = []
+            _ = _one_step(O, osde, fn, x, z, N, pred, i, one)
+            xm = coef[i, 0] * x + coef[i, 1] * p
+            xn = xm + coef[i, 2] * z
+            assert rel_mse(xm, one[0]) < 1e-10 and rel_mse(xn, one[1]) < 1e-10, (pred, i)
+
+
+def _one_step(O, osde, fn, x, z, N, pred, i, out):
+    """The oracle's update at step index i applied to x (uses its loop with a patched linspace start)."""
+    rec = []
+    ts = torch.linspace(1.0, 1e-6, N)
+    orig = torch.linspace
+    torch.linspace = lambda *a, **k: ts[i:i + 1].repeat(N)
+    try:
+        O.sample_discrete(osde, fn, x, [z] * N, 1 if False else N, predictor=pred, record=rec)
+    finally:
+        torch.linspace = orig
+    out.extend([rec[0][2], rec[0][3]])
+
+
+def test_sharding_bounds_and_padding():
+    from ldt_amd.dist import shard_bounds
+    from ldt_amd.trainer import _rows
+    for B, W in ((64, 8), (10, 4), (3, 2), (5, 8)):
+        seen = []
+        per0 = None
+        for r in range(W):
+            lo, hi, per = shard_bounds(B, r, W)
+            per0 = per0 or per
+            assert per == per0 and hi - lo == per
+            part = _rows(torch.arange(B)[:, None].float(), lo, hi, per)
+            assert part.shape[0] == per
+            seen += [int(v) for v in part[:max(0, min(hi, B) - lo), 0]]
+        assert seen == list(range(B))
+
+
+def test_ema_swap_semantics():
+    import ldt_amd
+    lin = torch.nn.Linear(4, 4)
+    ema = ldt_amd.EMAWeights(lin.parameters(), 0.999)
+    w0 = lin.weight.data.clone()
+    ema.swap_parameters_with_ema(True)                 # no 'ema' state: no-op (tools/utils.py:93-94)
+    assert torch.equal(lin.weight.data, w0)
+    ema.state[lin.weight] = {"ema": torch.ones(4, 4)}
+    ema.swap_parameters_with_ema(True)
+    assert torch.equal(lin.weight.data, torch.ones(4, 4)) and torch.equal(ema.state[lin.weight]["ema"], w0)
+    ema.swap_parameters_with_ema(True)
+    assert torch.equal(lin.weight.data, w0)
+
+
+def test_product_fails_loudly_without_gpu(tiny_cfg):
+    import ldt_amd
+    score = ldt_amd.Score(tiny_cfg.score)
+    with pytest.raises(RuntimeError):
+        score(torch.zeros(1, 8, 120), torch.ones(1))
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    with pytest.raises(RuntimeError):
+        comp.sample((1, 64), given_eps=torch.zeros(1, 8, 120))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldt_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("the CPU oracle", "").replace("CPU oracle", ""), f
+
+
+def test_unsupported_options_raise(tiny_cfg):
+    import copy
+    import ldt_amd
+    c = copy.deepcopy(tiny_cfg)
+    c.score.unet = True
+    with pytest.raises(NotImplementedError):
+        ldt_amd.Score(c.score)
+    c = copy.deepcopy(tiny_cfg)
+    c.compressor.pos_embedding = "mlp"
+    with pytest.raises(NotImplementedError):
+        ldt_amd.Compressor(c.compressor)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree not present")
+def test_default_init_draws_same_weights_as_reference(tiny_cfg):
+    """Same construction order => torch.manual_seed(s); Score(cfg)/Compressor(cfg) equal upstream's draws."""
+    import ldt_amd
+    from oracle import ref_import as R
+    R.setup()
+    from model.scorenet.score import Score as RScore
+    from model.Compressor.Network import Compressor as RComp
+    torch.manual_seed(7)
+    rs = RScore(tiny_cfg.score); rc = RComp(tiny_cfg.compressor)
+    torch.manual_seed(7)
+    ms = ldt_amd.Score(tiny_cfg.score); mc = ldt_amd.Compressor(tiny_cfg.compressor)
+    for a, b in ((rs, ms), (rc, mc)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
