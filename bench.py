@@ -29,6 +29,21 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-leve
 PEAK_HBM_GBS = 8000.0          # HBM3E spec, same table
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """progress to stderr (the JSON line on stdout stays alone)"""
+    print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +122,7 @@ def cpu_baseline(trainer, cfg, n_steps):
     same T and schedule, first `n_steps` of the 1000-step loop + one decode; per-step cost is
     step-invariant, so shapes/s(1000 steps) = B / (1000 * t_step + t_decode)."""
     from oracle import ldt_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = 4
     sd_s = {k: v.detach().float().cpu() for k, v in trainer.model.state_dict().items()}
@@ -115,6 +130,7 @@ def cpu_baseline(trainer, cfg, n_steps):
     x0, noises = O.draw_noises(1234, B, cfg.score.z_scale, cfg.score.z_dim, n_steps)
     sde = O.VPSDE(cfg.sde)
     fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd_s, cfg.score, x, t))
+    log("cpu baseline: %d threads, B=%d, %d steps" % (cores, B, n_steps))
     with torch.no_grad():
         t0 = time.time()
         eps = O.sample_discrete(sde, fn, x0, noises, cfg.sde.sample_N, max_steps=n_steps)
@@ -157,14 +173,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("model built on %s (world %d), B=%d T=%d N=%d" % (device, world, B, args.tokens, args.sde_steps))
+    for i in range(args.warmup):
         trainer.sample(B)
+        torch.cuda.synchronize()
+        log("warmup %d done" % i)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pts, eps = trainer.sample(B)
     barrier()
     dt = time.perf_counter() - t0
+    log("timed region: %.2f s for %d sample() calls" % (dt, args.steps))
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -189,6 +209,7 @@ def main():
         }
         if not args.no_roofline:
             roof, attn, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
+            log("roofline pass done: %s" % json.dumps(kernels))
             line["roofline"] = roof
             line["roofline_attention"] = attn
             line["kernels"] = kernels

@@ -100,6 +100,34 @@ int ldt_sampler_step(const float* x, const float* params, const float* noise, in
                      int64_t n, int64_t elem_offset, uint64_t seed, void* stream);
 int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, uint64_t seed, void* stream);
 
+/* ---- Compressor encoder front end (model/Compressor/layers.py:65-112, 288-319; Network.py:26-29,76,86-107) ----
+ * Clouds are fp32 [B][n][3]; index outputs are int32.
+ * ldt_fps: farthest point sampling, m centres per cloud, semantics of the vendored CUDA twin
+ *   model/functional/src/sampling/sampling.cu:86-167 (start index 0, ties to the smaller (k%512, k/512)).
+ *   The reference calls pointnet2_ops.furthest_point_sample (Compressor/layers.py:106; third party, not vendored).
+ * ldt_knn: k nearest points of each of the S centres by square_distance (layers.py:65-84) + topk(largest=False,
+ *   sorted=False) (:97): an UNORDERED index set [B][S][k]; dist_out (nullable) receives the [B][S][n] distances.
+ * ldt_group_normalize: LocalGrouper 'anchor' normalisation (:297-315): per-sample unbiased std of (g - anchor)
+ *   (stats: fp64 scratch [2*B]), rows U[b,s,j,:] = [alpha*(g-anchor)/(std+1e-5)+beta | centre feature], bf16, K padded to ldu.
+ * ldt_gather_rows: index_points (:46-62), out[b,s,:] = src[b, idx[b,s], :].
+ * ldt_maxpool: max over the middle axis of [G][n][C] (bf16 or fp32 input) -> fp32 [G][C] (:186, Network.py:97).
+ * ldt_actnorm: in place (x - shift[t,c]) * exp(-log_scale[t,c]) (model/layers.py:103-107, eval).
+ * ldt_reparam: mu|logvar split, clamp(logvar, lo, hi), eps = mu + exp(logvar/2)*noise into a strided slice
+ *   (Network.py:26-29,75-77); mu_out/logvar_out nullable.
+ * ldt_chamfer: distChamfer (evaluation/evaluation_metrics.py:23-33): dl[b][nb] = min over a, dr[b][na] = min over b. */
+int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream);
+int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_t S, int32_t k,
+            int32_t* idx_out, float* dist_out, void* stream);
+int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,
+                        const float* alpha, const float* beta, double* stats, int32_t B, int32_t n, int32_t S,
+                        int32_t k, int32_t D, uint16_t* U, int32_t ldu, void* stream);
+int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream);
+int ldt_maxpool(const void* in, int32_t in_bf16, int64_t ld, int64_t G, int32_t n, int32_t C, float* out, void* stream);
+int ldt_actnorm(float* x, const float* shift, const float* log_scale, int64_t B, int64_t per_sample, void* stream);
+int ldt_reparam(const float* post, const float* noise, float* out, int64_t ldo, float* mu_out, float* logvar_out,
+                int64_t rows, int32_t z, float lo, float hi, void* stream);
+int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na, int32_t nb, float* dl, float* dr, void* stream);
+
 /* ---- Score network forward: model/scorenet/score.py:117-151 (Transformer path, unet False) ------------- */
 typedef struct ldt_score_plan {
     int32_t hidden, heads, blocks, z_dim, z_pad, mlp_hidden, tokens, batch;

@@ -91,6 +91,18 @@ class DecoderBlock(_Holder):
         self.ln = nn.Conv1d(dim_z, dim_in, 1)
 
 
+def _fold_bn(conv, bn):
+    """Conv1d(k=1) followed by eval-mode BatchNorm1d(eps) == one affine map: W' = s W, b' = s (b - mean) + beta."""
+    s = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps))
+    w = conv_w(conv).detach().float() * s[:, None]
+    b = (conv.bias.detach().float() - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+    return w.contiguous(), b.contiguous()
+
+
+def _bf16_panel(w):
+    return ops.cast_pad_bf16(w.contiguous(), ops.pad64(w.shape[1]))
+
+
 # ----------------------------------------------------------------------------- Compressor
 class Compressor(nn.Module):
     def __init__(self, cfg):
@@ -163,6 +175,21 @@ class Compressor(nn.Module):
             P["w_out"], P["b_out"] = f32(conv_w(self.output)), f32(self.output.bias)
             P["w_input"], P["b_input"] = f32(conv_w(self.input)), f32(self.input.bias)
             P["prior"] = f32(self.init_set.prior)
+            # LocalGrouper: eval-mode BatchNorm folded into the preceding 1x1 conv (Compressor/layers.py:115-160)
+            ex = self.group.extraction
+            D = self.hidden_dim
+            P["alpha"], P["beta"] = f32(self.group.affine_alpha.reshape(-1)), f32(self.group.affine_beta.reshape(-1))
+            w1, b1 = _fold_bn(ex.transfer.net[0], ex.transfer.net[1])
+            P["w_pre1"], P["b_pre1"] = _bf16_panel(w1), b1
+            w2, b2 = _fold_bn(ex.operation[0].net1[0], ex.operation[0].net1[1])
+            P["w_pre2"], P["b_pre2"] = _bf16_panel(w2), b2
+            P["w_pre3"], P["b_pre3"] = _bf16_panel(f32(conv_w(ex.operation[0].net2[0]))), f32(ex.operation[0].net2[0].bias)
+            # MiniPointnet (Network.py:86-101), fp32
+            pe = self.pos_embedding
+            P["w_pe1"], P["b_pe1"] = _fold_bn(pe.conv1, pe.bn1)
+            P["w_pe2"], P["b_pe2"] = _fold_bn(pe.conv2, pe.bn2)
+            P["w_pefc"], P["b_pefc"] = f32(pe.fc.weight), f32(pe.fc.bias)
+            P["an_shift"], P["an_logs"] = f32(self.conv_in.shift.reshape(-1)), f32(self.conv_in.log_scale.reshape(-1))
         self._pack, self._pack_key = P, key
         return P
 
@@ -226,5 +253,71 @@ class Compressor(nn.Module):
     def encode(self, x, **kw):
         return self.forward(x, **kw)["all_eps"]
 
-    def forward(self, x, num_points=None, label=None):
-        raise NotImplementedError("Compressor.forward (encode) lands with the FPS/kNN kernels")
+    # ------------------------------------------------------------------ encode (Network.py:188-249)
+    @torch.no_grad()
+    def forward(self, x, num_points=None, label=None, *, post_noise=None, want_stats=False):
+        """Bidirectional inference: x (B, N, 3) -> dict with 'all_eps' (B, tokens, n_layers*z_dim) and the
+        reconstruction 'set' (B, N, 3).  `post_noise`: optional list of n_layers tensors (B, tokens, z_dim) replacing
+        the N(0,1) draws of `sample(mu, logvar)` (Network.py:26-29).  Training-only entries of the reference dict
+        ('kls', 'all_logqz') are not produced; 'posteriors' holds token-major (mu, logvar) when want_stats."""
+        from ._lib import ACT_RELU, EPI_RELU_BF16
+        if label is not None:
+            raise NotImplementedError("class-conditional Compressor is not on the shipped path")
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("Compressor.forward: parameters on %s; the HIP path has no CPU fallback" % dev)
+        B, N, _ = x.shape
+        T, D, z, L = self.z_scales, self.hidden_dim, self.z_dim, self.n_layers
+        npts = self.outsize if num_points is None else num_points
+        # CPU generator stream in the reference's order: B randperms (InitialSet, :215) then one randn per level (:220)
+        presence = [torch.randperm(self.max_outputs) < npts for _ in range(B)]
+        keep_mask = torch.stack(presence, 0) if npts != self.max_outputs else None
+        if post_noise is None:
+            post_noise = [torch.randn((B, z, T)).transpose(1, 2) for _ in range(L)]
+        P = self.packed()
+        pts = x.to(dev, torch.float32).contiguous()
+        k = N // T * 2                                                              # Network.py:195
+        # ---- bottom_up: input conv, FPS + kNN grouping, PreExtraction, pos embedding, ActNorm, encoder stages
+        feat = ops.sgemm(pts.view(B * N, 3), P["w_input"], P["b_input"])            # Conv1d 3 -> D  (:192)
+        fps_idx = ops.fps(pts, T)
+        centers = ops.gather_rows(pts, fps_idx)                                     # [B,T,3]
+        knn_idx = ops.knn(pts, centers, k)
+        U = ops.group_normalize(feat.view(B, N, D), pts, fps_idx, knn_idx, P["alpha"], P["beta"])
+        h1 = ops.gemm_bf16(U, P["w_pre1"], P["b_pre1"], EPI_RELU_BF16)              # transfer: Conv+BN+ReLU
+        r = ops.gemm_bf16(h1, P["w_pre2"], P["b_pre2"], EPI_RELU_BF16)              # net1: Conv+BN+ReLU
+        h2 = ops.gemm_bf16(r, P["w_pre3"], P["b_pre3"], EPI_RELU_BF16, skip=h1)     # act(net2(.) + x)
+        tok = ops.maxpool(h2, B * T, k)                                             # max over the k neighbours
+        tok_pre = tok.clone() if want_stats else None
+        c1 = ops.sgemm(centers.view(B * T, 3), P["w_pe1"], P["b_pe1"], act_out=ACT_RELU)
+        c2 = ops.sgemm(c1, P["w_pe2"], P["b_pe2"], act_out=ACT_RELU)
+        pos = ops.sgemm(ops.maxpool(c2, B, T), P["w_pefc"], P["b_pefc"])            # [B, p_dim]
+        ops.actnorm_(tok, P["an_shift"], P["an_logs"], B)
+        enc_out = []
+        for Pe in P["enc"]:                                                         # Network.py:203-205, 41-45
+            for Pa in Pe["atts"]:
+                residual_block(Pa, tok, B, T, y_bf16=ops.cast_pad_bf16(tok, ops.pad64(D)), Nk=T, c=pos)
+            enc_out.append(final_layer(Pe["out"], tok, B, T, pos))
+        # ---- top_down: posterior per level + decoder block
+        o = self._initial_set(P, B, npts, keep_mask)
+        all_eps = torch.empty((B * T, L * z), dtype=torch.float32, device=dev)
+        stats = []
+        for j in range(L):
+            Pd = P["dec"][L - 1 - j]
+            xj = enc_out[-j - 1].clone()
+            if j == 0:
+                y, nk = ops.cast_pad_bf16(xj, ops.pad64(D)), T                       # compute_posterior(x, None): att(x, x)
+            else:
+                y, nk = ops.cast_pad_bf16(o, ops.pad64(D)), npts                    # att(x, o): K/V = 2048 decoded points
+            residual_block(Pd["att"], xj, B, T, y_bf16=y, Nk=nk)
+            post = ops.sgemm(xj, Pd["w_prior"], Pd["b_prior"], act_in=ACT_SILU)      # SiLU -> Conv1d D -> 2z
+            nz = post_noise[j].to(dev, torch.float32).contiguous().view(B * T, z)
+            ej = all_eps[:, z * j: z * (j + 1)]
+            stats.append(ops.reparam(post, nz, ej, self.min_sigma, 10., want_stats))
+            self._decoder_level(Pd, o, ej, B, npts, T)
+        out = ops.sgemm(o, P["w_out"], P["b_out"]).view(B, npts, 3)
+        res = {"set": self.postprocess(out), "all_eps": all_eps.view(B, T, L * z), "max": tok.max(),
+               "posteriors": [(all_eps.view(B, T, L * z)[..., z * j: z * (j + 1)],) + tuple(
+                   None if t is None else t.view(B, T, z) for t in stats[j]) for j in range(L)],
+               "kls": None, "all_logqz": None,
+               "fps_idx": fps_idx, "knn_idx": knn_idx, "centers": centers, "tokens": tok_pre}
+        return res

@@ -101,6 +101,44 @@ extern "C" int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int
     return ldt_philox_normal_launch(out, n, elem_offset, step, (uint32_t)seed, (uint32_t)(seed >> 32), ST(stream));
 }
 
+// ------------------------------------------------------------------------------ Compressor encoder front end
+extern "C" int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream) {
+    LDT_REQUIRE(xyz && idx_out, LDT_EARG, "fps: null pointer");
+    return ldt_fps_launch(xyz, B, n, m, idx_out, ST(stream));
+}
+extern "C" int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_t S, int32_t k,
+                       int32_t* idx_out, float* dist_out, void* stream) {
+    LDT_REQUIRE(xyz && centers && idx_out, LDT_EARG, "knn: null pointer");
+    return ldt_knn_launch(xyz, centers, B, n, S, k, idx_out, dist_out, ST(stream));
+}
+extern "C" int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,
+                                   const float* alpha, const float* beta, double* stats, int32_t B, int32_t n, int32_t S,
+                                   int32_t k, int32_t D, uint16_t* U, int32_t ldu, void* stream) {
+    LDT_REQUIRE(feat && xyz && fps_idx && knn_idx && alpha && beta && stats && U, LDT_EARG, "group: null pointer");
+    return ldt_group_launch(feat, xyz, fps_idx, knn_idx, alpha, beta, stats, B, n, S, k, D, BFM(U), ldu, ST(stream));
+}
+extern "C" int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream) {
+    LDT_REQUIRE(src && idx && out, LDT_EARG, "gather_rows: null pointer");
+    return ldt_gather_rows_launch(src, idx, B, n, S, C, out, ST(stream));
+}
+extern "C" int ldt_maxpool(const void* in, int32_t in_bf16, int64_t ld, int64_t G, int32_t n, int32_t C, float* out, void* stream) {
+    LDT_REQUIRE(in && out, LDT_EARG, "maxpool: null pointer");
+    return ldt_maxpool_launch(in, in_bf16, ld, G, n, C, out, ST(stream));
+}
+extern "C" int ldt_actnorm(float* x, const float* shift, const float* log_scale, int64_t B, int64_t per_sample, void* stream) {
+    LDT_REQUIRE(x && shift && log_scale, LDT_EARG, "actnorm: null pointer");
+    return ldt_actnorm_launch(x, shift, log_scale, B, per_sample, ST(stream));
+}
+extern "C" int ldt_reparam(const float* post, const float* noise, float* out, int64_t ldo, float* mu_out, float* logvar_out,
+                           int64_t rows, int32_t z, float lo, float hi, void* stream) {
+    LDT_REQUIRE(post && noise && out, LDT_EARG, "reparam: null pointer");
+    return ldt_reparam_launch(post, noise, out, ldo, mu_out, logvar_out, rows, z, lo, hi, ST(stream));
+}
+extern "C" int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na, int32_t nb, float* dl, float* dr, void* stream) {
+    LDT_REQUIRE(a && b && dl && dr, LDT_EARG, "chamfer: null pointer");
+    return ldt_chamfer_launch(a, b, B, na, nb, dl, dr, ST(stream));
+}
+
 // ------------------------------------------------------------------------------ Score forward
 static int check_plan(const ldt_score_plan* p) {
     LDT_REQUIRE(p, LDT_EARG, "score: null plan");
@@ -223,25 +261,52 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
             TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, s));
         return LDT_OK;
     }
-    // one step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter
+    // One step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter.
+    // Capture runs on a private non-blocking stream (the caller's may be the legacy default stream, which
+    // cannot be captured), fenced against the caller's stream with events on both sides.
+    hipStream_t gs = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) { ldt_set_error("sample_loop: begin capture: %s", hipGetErrorString(e)); return (int)e; }
-    const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, s);
-    e = hipStreamEndCapture(s, &graph);
-    if (rc != LDT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (e != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(e)); return (int)e; }
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(graph); ldt_set_error("sample_loop: instantiate: %s", hipGetErrorString(e)); return (int)e; }
     int status = LDT_OK;
-    for (int i = 0; i < n_steps; ++i) {
-        e = hipGraphLaunch(exec, s);
-        if (e != hipSuccess) { ldt_set_error("sample_loop: graph launch %d: %s", i, hipGetErrorString(e)); status = (int)e; break; }
+#define HIPTRY(call, what)                                                                   \
+    do {                                                                                     \
+        const hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess && status == LDT_OK) {                                          \
+            ldt_set_error("sample_loop: %s: %s", what, hipGetErrorString(_e));               \
+            status = (int)_e;                                                                \
+        }                                                                                    \
+    } while (0)
+    HIPTRY(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking), "stream create");
+    HIPTRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming), "event create");
+    HIPTRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming), "event create");
+    if (status == LDT_OK) {
+        HIPTRY(hipEventRecord(ev_in, s), "event record");
+        HIPTRY(hipStreamWaitEvent(gs, ev_in, 0), "stream wait");
     }
-    // the exec must outlive its in-flight launches
-    (void)hipStreamSynchronize(s);
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
+    if (status == LDT_OK) {
+        HIPTRY(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal), "begin capture");
+        if (status == LDT_OK) {
+            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, gs);
+            const hipError_t ee = hipStreamEndCapture(gs, &graph);
+            if (rc != LDT_OK) status = rc;
+            else if (ee != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(ee)); status = (int)ee; }
+        }
+    }
+    if (status == LDT_OK) HIPTRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "graph instantiate");
+    for (int i = 0; i < n_steps && status == LDT_OK; ++i) HIPTRY(hipGraphLaunch(exec, gs), "graph launch");
+    if (gs) {
+        if (status == LDT_OK) {
+            HIPTRY(hipEventRecord(ev_out, gs), "event record");
+            HIPTRY(hipStreamWaitEvent(s, ev_out, 0), "stream wait");
+        }
+        (void)hipStreamSynchronize(gs);          // the exec must outlive its in-flight launches
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (gs) (void)hipStreamDestroy(gs);
+#undef HIPTRY
     return status;
 }

@@ -181,16 +181,24 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
             z = (f32x4){z0, z1, z2, z3};
         }
         f32x4 xm, xn;
+        {
+#pragma clang fp contract(off)      // the reference's separate mul/add/div roundings, no FMA (HIP's __f*_rn are plain ops)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (a.mode == 0) {
-                const float score = __fdiv_rn(-p[j], cf[1]);
-                xm[j] = __fdiv_rn(__fadd_rn(x[j], __fmul_rn(cf[0], score)), cf[2]);
-            } else {
-                xm[j] = __fadd_rn(__fmul_rn(cf[0], x[j]), __fmul_rn(cf[1], p[j]));
+            for (int j = 0; j < 4; ++j) {
+                if (a.mode == 0) {
+                    const float score = -p[j] / cf[1];
+                    const float bs = cf[0] * score;
+                    const float num = x[j] + bs;
+                    xm[j] = num / cf[2];
+                } else {
+                    const float ax = cf[0] * x[j];
+                    const float bp = cf[1] * p[j];
+                    xm[j] = ax + bp;
+                }
+                const float cz = (a.mode == 0) ? cf[3] : cf[2];
+                const float nz_ = cz * z[j];
+                xn[j] = xm[j] + nz_;
             }
-            const float cz = (a.mode == 0) ? cf[3] : cf[2];
-            xn[j] = __fadd_rn(xm[j], __fmul_rn(cz, z[j]));
         }
         *reinterpret_cast<f32x4*>(a.x_out + 4 * i) = xn;
         if (a.x_mean_out) *reinterpret_cast<f32x4*>(a.x_mean_out + 4 * i) = xm;

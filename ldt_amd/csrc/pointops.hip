@@ -1,0 +1,356 @@
+// Point-cloud front end of the Compressor encoder (gfx950): farthest point sampling, kNN (distance + top-k
+// selection), neighbourhood gather + anchor normalisation, max-pooling, ActNorm and the reparameterised
+// posterior draw.  Integer/index work is exact; floating point follows the operation order stated per kernel.
+// Reference: model/Compressor/layers.py:65-112 (square_distance / knn_point / cluster), :288-319
+// (LocalGrouper.forward), model/functional/src/sampling/sampling.cu:86-167 (FPS twin), Network.py:26-29,76.
+#include "kernels.h"
+
+#define TRY_LAUNCH(what) do { const int _rc = ldt_check_launch(what); if (_rc != LDT_OK) return _rc; } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// FPS: one 512-thread workgroup per cloud; points and running min-distances live in registers
+// (PPT points per thread, point k = tid + 512*j), the per-iteration argmax is a wave shuffle
+// reduction + one LDS hop across the 8 waves.  Semantics = the vendored CUDA twin: start at index 0,
+// distances initialised to 1e38, d = (dx*dx + dy*dy) + dz*dz without FMA contraction, running min,
+// argmax; a tie goes to the smaller (k % 512, k / 512)  (sampling.cu:141-158: strict '>' per thread, then a
+// pairwise tree that keeps the lower thread on equality).
+struct Cand { float d; int k; };
+__device__ __forceinline__ bool beats(float da, int ka, float db, int kb) {
+    // both candidates come from the same 512-stride layout: rank = (k & 511, k >> 9)
+    if (da != db) return da > db;
+    const int ra = ((ka & 511) << 16) | (ka >> 9), rb = ((kb & 511) << 16) | (kb >> 9);
+    return ra < rb;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+    __shared__ float s_d[8];
+    __shared__ int s_k[8];
+    __shared__ float s_pt[3];
+    __shared__ int s_old;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = xyz + (long)b * n * 3;
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int k = tid + 512 * j;
+        const bool in = k < n;
+        px[j] = in ? p[3 * k] : 0.f; py[j] = in ? p[3 * k + 1] : 0.f; pz[j] = in ? p[3 * k + 2] : 0.f;
+        dist[j] = 1e38f;
+    }
+    if (tid == 0) { idx_out[(long)b * m] = 0; s_pt[0] = p[0]; s_pt[1] = p[1]; s_pt[2] = p[2]; }
+    __syncthreads();
+    for (int it = 1; it < m; ++it) {
+        const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
+        float best = -1.f; int besti = 0;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int k = tid + 512 * j;
+                if (k < n) {
+                    const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
+                    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    const float s = xx + yy;
+                    const float d = s + zz;
+                    const float d2 = fminf(d, dist[j]);
+                    dist[j] = d2;
+                    if (d2 > best) { best = d2; besti = k; }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(best, o, 64);
+            const int ok = __shfl_xor(besti, o, 64);
+            if (beats(od, ok, best, besti)) { best = od; besti = ok; }
+        }
+        __syncthreads();                     // s_pt consumed by everyone
+        if (lane == 0) { s_d[wave] = best; s_k[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            float bd = s_d[0]; int bk = s_k[0];
+            for (int w = 1; w < 8; ++w) if (beats(s_d[w], s_k[w], bd, bk)) { bd = s_d[w]; bk = s_k[w]; }
+            s_old = bk;
+            idx_out[(long)b * m + it] = bk;
+            s_pt[0] = p[3 * bk]; s_pt[1] = p[3 * bk + 1]; s_pt[2] = p[3 * bk + 2];
+        }
+        __syncthreads();
+    }
+}
+
+int ldt_fps_launch(const float* xyz, int B, int n, int m, int* idx, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 0 && m > 0 && m <= n, LDT_ESHAPE, "fps: B=%d n=%d m=%d", B, n, m);
+    LDT_REQUIRE(n <= 512 * 16, LDT_ESHAPE, "fps: n=%d > 8192 points per cloud not built", n);
+    if (n <= 512 * 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(512), 0, s, xyz, n, m, idx);
+    else hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(512), 0, s, xyz, n, m, idx);
+    return ldt_check_launch("fps");
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN: one wave per query centre.  d(c,p) = ((-2 * (c.p)) + |c|^2) + |p|^2 (square_distance, layers.py:81-83),
+// c.p and the norms accumulated x,y,z in order with FMA.  The k smallest are selected exactly with a 32-step
+// radix select over order-preserving integer keys (wave-wide counts), ties at the k-th value resolved towards
+// the smaller point index; the result is an UNORDERED index set like topk(sorted=False) (:97).
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int PPL>   // points per lane: n <= 64*PPL
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, const float* __restrict__ centers,
+                                                  int n, int S, long nq, int k, int* __restrict__ out, float* __restrict__ dist_out) {
+    const int lane = threadIdx.x & 63;
+    const long q = blockIdx.x * 4L + (threadIdx.x >> 6);        // global centre id in [0, B*S)
+    if (q >= nq) return;
+    const int b = (int)(q / S);
+    const float* p = xyz + (long)b * n * 3;
+    const float cx = centers[q * 3], cy = centers[q * 3 + 1], cz = centers[q * 3 + 2];
+    const float cn = fmaf(cz, cz, fmaf(cy, cy, cx * cx));
+    uint32_t key[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n) {
+            const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+            const float dot = fmaf(cz, z, fmaf(cy, y, cx * x));
+            const float pn = fmaf(z, z, fmaf(y, y, x * x));
+            float d;
+            {
+#pragma clang fp contract(off)
+                d = -2.f * dot;
+                d = d + cn;
+                d = d + pn;
+            }
+            key[j] = fkey(d);
+            if (dist_out) dist_out[q * n + i] = d;
+        } else key[j] = 0xFFFFFFFFu;
+    }
+    // radix select: the k-th smallest key
+    uint32_t prefix = 0;
+    int need = k;
+    for (int bit = 31; bit >= 0; --bit) {
+        int c0 = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const bool match = (bit == 31) || (((key[j] ^ prefix) >> (bit + 1)) == 0);
+            c0 += (match && !((key[j] >> bit) & 1u)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o, 64);
+        if (c0 >= need) { /* k-th has this bit 0 */ }
+        else { prefix |= (1u << bit); need -= c0; }
+    }
+    // emit: all keys < kth, then `need` keys == kth in index order
+    int* o = out + q * (long)k;
+    int base = 0;
+    int lt_total = 0;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const bool sel = key[j] < prefix;
+        const unsigned long long bal = __ballot(sel);
+        if (sel) o[base + __popcll(bal & ((1ull << lane) - 1ull))] = lane + 64 * j;
+        base += __popcll(bal);
+    }
+    lt_total = base;
+    int eq_left = k - lt_total;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const bool eq = (key[j] == prefix) && (lane + 64 * j < n);
+        const unsigned long long bal = __ballot(eq);
+        const int r = __popcll(bal & ((1ull << lane) - 1ull));
+        if (eq && r < eq_left) o[base + r] = lane + 64 * j;
+        const int took = min(eq_left, (int)__popcll(bal));
+        base += took; eq_left -= took;
+    }
+}
+
+int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, int k, int* out, float* dist_out, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 0 && S > 0 && k > 0 && k <= n, LDT_ESHAPE, "knn: B=%d n=%d S=%d k=%d", B, n, S, k);
+    LDT_REQUIRE(n <= 64 * 128, LDT_ESHAPE, "knn: n=%d > 8192 points per cloud not built", n);
+    const long nq = (long)B * S;
+    dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (n <= 64 * 32) hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, xyz, centers, n, S, nq, k, out, dist_out);
+    else hipLaunchKernelGGL(knn_kernel<128>, grid, block, 0, s, xyz, centers, n, S, nq, k, out, dist_out);
+    return ldt_check_launch("knn");
+}
+
+// ------------------------------------------------------------------------------------------------
+// LocalGrouper (layers.py:297-315), 'anchor' normalisation.  Two kernels:
+//  (1) per-sample sum / sum-of-squares of (g - anchor) over all S*k*(D+3) elements, fp64 accumulation
+//      (the unbiased std of torch.std(..., dim=-1), :311);
+//  (2) rows U[b,s,j,:] = [ alpha*(g - anchor)/(std+1e-5) + beta | centre feature ] as bf16, K-padded for the
+//      MFMA GEMM of PreExtraction (:315, :178-187).
+// feat [B*n, D] fp32 (input conv), xyz [B*n, 3]; fps_idx [B,S], knn_idx [B,S,k] int32.
+__global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                          const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
+                                                          int n, int S, int k, int D, double* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)S * k;
+    double s1 = 0.0, s2 = 0.0;
+    for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4L) {
+        const int sidx = (int)(r / k);
+        const int ci = fps_idx[(long)b * S + sidx];
+        const int pi = knn_idx[((long)b * S + sidx) * k + (r % k)];
+        const float* fg = feat + ((long)b * n + pi) * D;
+        const float* fa = feat + ((long)b * n + ci) * D;
+        for (int c = lane; c < D + 3; c += 64) {
+            float g, a;
+            if (c < D) { g = fg[c]; a = fa[c]; }
+            else { g = xyz[((long)b * n + pi) * 3 + (c - D)]; a = xyz[((long)b * n + ci) * 3 + (c - D)]; }
+            const float d = g - a;
+            s1 += (double)d; s2 += (double)d * (double)d;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) { atomicAdd(&stats[2 * b], s1); atomicAdd(&stats[2 * b + 1], s2); }
+}
+
+__global__ __launch_bounds__(256) void group_build_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                          const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
+                                                          const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                          const double* __restrict__ stats, int n, int S, int k, int D,
+                                                          bf16_t* __restrict__ U, int ldu) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)S * k;
+    const double cnt = (double)rows * (D + 3);
+    const double mean = stats[2 * b] / cnt;
+    const double var = (stats[2 * b + 1] - cnt * mean * mean) / (cnt - 1.0);
+    const float inv = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-5f);
+    for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4L) {
+        const int sidx = (int)(r / k);
+        const int ci = fps_idx[(long)b * S + sidx];
+        const int pi = knn_idx[((long)b * S + sidx) * k + (r % k)];
+        const float* fg = feat + ((long)b * n + pi) * D;
+        const float* fa = feat + ((long)b * n + ci) * D;
+        bf16_t* u = U + ((long)b * rows + r) * ldu;
+        for (int c = lane; c < ldu; c += 64) {
+            float v = 0.f;
+            if (c < D + 3) {
+                float g, a;
+                if (c < D) { g = fg[c]; a = fa[c]; }
+                else { g = xyz[((long)b * n + pi) * 3 + (c - D)]; a = xyz[((long)b * n + ci) * 3 + (c - D)]; }
+                v = alpha[c] * ((g - a) * inv) + beta[c];
+            } else if (c < 2 * D + 3) {
+                v = fa[c - (D + 3)];
+            }
+            u[c] = (bf16_t)v;
+        }
+    }
+}
+
+int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
+                     const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 0 && S > 0 && k > 0 && D > 0 && ldu >= 2 * D + 3, LDT_ESHAPE, "group: bad shape");
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s);
+    if (e != hipSuccess) { ldt_set_error("group: memset: %s", hipGetErrorString(e)); return (int)e; }
+    const long rows = (long)S * k;
+    int bx = (int)((rows + 3) / 4); if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(group_stats_kernel, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, D, stats);
+    TRY_LAUNCH("group_stats");
+    hipLaunchKernelGGL(group_build_kernel, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, n, S, k, D, U, ldu);
+    return ldt_check_launch("group_build");
+}
+
+// gather rows: out[b,s,:] = src[b, idx[b,s], :]   (index_points, layers.py:46-62) fp32
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n, int S, int C,
+                                   float* __restrict__ out, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C; const int c = (int)(i % C);
+        const long b = row / S;
+        out[i] = src[(b * n + idx[row]) * C + c];
+    }
+}
+int ldt_gather_rows_launch(const float* src, const int* idx, int B, int n, int S, int C, float* out, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 0 && S > 0 && C > 0, LDT_ESHAPE, "gather_rows: bad shape");
+    const long total = (long)B * S * C;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, idx, n, S, C, out, total);
+    return ldt_check_launch("gather_rows");
+}
+
+// max over the middle axis: in [G][n][C] (bf16 or fp32) -> out fp32 [G][C]   (adaptive_max_pool1d :186; MiniPointnet max :97)
+template <typename TI>
+__global__ void maxpool_kernel(const TI* __restrict__ in, long ld, int n, int C, float* __restrict__ out, long G) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < G * C; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / C; const int c = (int)(i % C);
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) m = fmaxf(m, (float)in[(g * n + j) * ld + c]);
+        out[i] = m;
+    }
+}
+int ldt_maxpool_launch(const void* in, int in_bf16, long ld, long G, int n, int C, float* out, hipStream_t s) {
+    LDT_REQUIRE(G > 0 && n > 0 && C > 0 && ld >= C, LDT_ESHAPE, "maxpool: bad shape");
+    long blocks = (G * C + 255) / 256; if (blocks > 4096) blocks = 4096;
+    if (in_bf16) hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)in, ld, n, C, out, G);
+    else hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in, ld, n, C, out, G);
+    return ldt_check_launch("maxpool");
+}
+
+// ActNorm (model/layers.py:103-107, eval): y[b,t,c] = (x[b,t,c] - shift[t,c]) * exp(-log_scale[t,c]), in place
+__global__ void actnorm_kernel(float* __restrict__ x, const float* __restrict__ shift, const float* __restrict__ log_scale,
+                               long total, long per_sample) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long j = i % per_sample;
+        x[i] = (x[i] - shift[j]) * expf(-log_scale[j]);
+    }
+}
+int ldt_actnorm_launch(float* x, const float* shift, const float* log_scale, long B, long per_sample, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && per_sample > 0, LDT_ESHAPE, "actnorm: bad shape");
+    const long total = B * per_sample;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(actnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, shift, log_scale, total, per_sample);
+    return ldt_check_launch("actnorm");
+}
+
+// posterior draw (Network.py:26-29,75-77): mu = post[:, :z], logvar = clamp(post[:, z:], lo, hi);
+// eps = mu + exp(logvar / 2) * noise   -> written into a strided slice of all_eps
+__global__ void reparam_kernel(const float* __restrict__ post, const float* __restrict__ noise, float* __restrict__ out,
+                               long ldo, float* __restrict__ mu_out, float* __restrict__ lv_out, long rows, int z, float lo, float hi) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows * z; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / z; const int c = (int)(i % z);
+        const float mu = post[r * 2 * z + c];
+        const float lv = fminf(fmaxf(post[r * 2 * z + z + c], lo), hi);
+        out[r * ldo + c] = mu + expf(lv / 2.f) * noise[i];
+        if (mu_out) { mu_out[i] = mu; lv_out[i] = lv; }
+    }
+}
+int ldt_reparam_launch(const float* post, const float* noise, float* out, long ldo, float* mu_out, float* lv_out,
+                       long rows, int z, float lo, float hi, hipStream_t s) {
+    LDT_REQUIRE(rows > 0 && z > 0 && ldo >= z, LDT_ESHAPE, "reparam: bad shape");
+    LDT_REQUIRE((mu_out == nullptr) == (lv_out == nullptr), LDT_EARG, "reparam: mu/logvar outputs go together");
+    long blocks = (rows * z + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reparam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, post, noise, out, ldo, mu_out, lv_out, rows, z, lo, hi);
+    return ldt_check_launch("reparam");
+}
+
+// Chamfer distance (evaluation/evaluation_metrics.py:23-33,88): dl[b,j] = min_i |a_i - b_j|^2, dr[b,i] = min_j |a_i - b_j|^2
+// with the reference's expanded form |a|^2 + |b|^2 - 2 a.b.  One thread per query point.
+__global__ void chamfer_min_kernel(const float* __restrict__ q, const float* __restrict__ ref, int nq, int nr, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float* qp = q + ((long)b * nq + i) * 3;
+    const float x = qp[0], y = qp[1], z = qp[2];
+    const float qn = fmaf(z, z, fmaf(y, y, x * x));
+    float m = INFINITY;
+    const float* rp = ref + (long)b * nr * 3;
+    for (int j = 0; j < nr; ++j) {
+        const float rx = rp[3 * j], ry = rp[3 * j + 1], rz = rp[3 * j + 2];
+        const float rn = fmaf(rz, rz, fmaf(ry, ry, rx * rx));
+        const float dot = fmaf(z, rz, fmaf(y, ry, x * rx));
+        m = fminf(m, (qn + rn) - 2.f * dot);
+    }
+    out[(long)b * nq + i] = m;
+}
+int ldt_chamfer_launch(const float* a, const float* b, int B, int na, int nb, float* dl, float* dr, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && na > 0 && nb > 0, LDT_ESHAPE, "chamfer: bad shape");
+    // dl (P.min(1)): for every point of b the nearest a ; dr (P.min(2)): for every point of a the nearest b
+    hipLaunchKernelGGL(chamfer_min_kernel, dim3((nb + 255) / 256, B), dim3(256), 0, s, b, a, nb, na, dl);
+    TRY_LAUNCH("chamfer_dl");
+    hipLaunchKernelGGL(chamfer_min_kernel, dim3((na + 255) / 256, B), dim3(256), 0, s, a, b, na, nb, dr);
+    return ldt_check_launch("chamfer_dr");
+}

@@ -139,3 +139,83 @@ def philox_normal(shape, device, seed, step=0, elem_offset=0):
     out = torch.empty(shape, dtype=torch.float32, device=device)
     check(lib().ldt_philox_normal(_p(out), out.numel(), elem_offset, step, seed, stream_ptr()), "ldt_philox_normal")
     return out
+
+
+# ----------------------------------------------------------------------------- Compressor encoder front end
+def fps(xyz, m):
+    """xyz fp32 [B,n,3] -> int32 [B,m] (farthest point sampling, start index 0)."""
+    _need(xyz, torch.float32, "xyz")
+    xyz = xyz.contiguous()
+    B, n, _ = xyz.shape
+    idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
+    check(lib().ldt_fps(_p(xyz), B, n, m, _p(idx), stream_ptr()), "ldt_fps")
+    return idx
+
+
+def knn(xyz, centers, k, return_dist=False):
+    """-> int32 [B,S,k] unordered nearest-neighbour sets (+ the [B,S,n] distances)."""
+    _need(xyz, torch.float32, "xyz"); _need(centers, torch.float32, "centers")
+    xyz, centers = xyz.contiguous(), centers.contiguous()
+    B, n, _ = xyz.shape
+    S = centers.shape[1]
+    idx = torch.empty((B, S, k), dtype=torch.int32, device=xyz.device)
+    dist = torch.empty((B, S, n), dtype=torch.float32, device=xyz.device) if return_dist else None
+    check(lib().ldt_knn(_p(xyz), _p(centers), B, n, S, k, _p(idx), _p(dist), stream_ptr()), "ldt_knn")
+    return (idx, dist) if return_dist else idx
+
+
+def group_normalize(feat, xyz, fps_idx, knn_idx, alpha, beta):
+    """LocalGrouper 'anchor' rows: -> bf16 [B*S*k, pad64(2D+3)]."""
+    B, n, D = feat.shape
+    S, k = knn_idx.shape[1], knn_idx.shape[2]
+    ldu = pad64(2 * D + 3)
+    U = torch.empty((B * S * k, ldu), dtype=torch.bfloat16, device=feat.device)
+    stats = torch.empty((2 * B,), dtype=torch.float64, device=feat.device)
+    check(lib().ldt_group_normalize(_p(feat), _p(xyz), _p(fps_idx), _p(knn_idx), _p(alpha), _p(beta), _p(stats), B, n, S, k, D,
+                                    _p(U), ldu, stream_ptr()), "ldt_group_normalize")
+    return U
+
+
+def gather_rows(src, idx):
+    """src fp32 [B,n,C], idx int32 [B,S] -> [B,S,C]."""
+    B, n, Cc = src.shape
+    S = idx.shape[1]
+    out = torch.empty((B, S, Cc), dtype=torch.float32, device=src.device)
+    check(lib().ldt_gather_rows(_p(src.contiguous()), _p(idx), B, n, S, Cc, _p(out), stream_ptr()), "ldt_gather_rows")
+    return out
+
+
+def maxpool(x, G, n):
+    """x [G*n, C] (bf16 or fp32, row stride respected) -> fp32 [G, C] max over n."""
+    Cc = x.shape[1]
+    out = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
+    check(lib().ldt_maxpool(_p(x), int(x.dtype == torch.bfloat16), x.stride(0), G, n, Cc, _p(out), stream_ptr()), "ldt_maxpool")
+    return out
+
+
+def actnorm_(x, shift, log_scale, B):
+    """in place on x fp32 [B*T, C] with per-token parameters [T*C]."""
+    check(lib().ldt_actnorm(_p(x), _p(shift), _p(log_scale), B, x.numel() // B, stream_ptr()), "ldt_actnorm")
+    return x
+
+
+def reparam(post, noise, out, lo, hi, want_stats=False):
+    """post fp32 [rows, 2z], noise [rows, z] -> out[rows, z] (strided slice ok) = mu + exp(clamp(logvar)/2)*noise."""
+    rows, z2 = post.shape
+    z = z2 // 2
+    mu = torch.empty((rows, z), dtype=torch.float32, device=post.device) if want_stats else None
+    lv = torch.empty_like(mu) if want_stats else None
+    check(lib().ldt_reparam(_p(post), _p(noise), _p(out), out.stride(0), _p(mu), _p(lv), rows, z, float(lo), float(hi),
+                            stream_ptr()), "ldt_reparam")
+    return mu, lv
+
+
+def chamfer(a, b):
+    """a [B,na,3], b [B,nb,3] fp32 -> (dl [B,nb], dr [B,na]) squared nearest-neighbour distances."""
+    a, b = a.contiguous(), b.contiguous()
+    B, na, _ = a.shape
+    nb = b.shape[1]
+    dl = torch.empty((B, nb), dtype=torch.float32, device=a.device)
+    dr = torch.empty((B, na), dtype=torch.float32, device=a.device)
+    check(lib().ldt_chamfer(_p(a), _p(b), B, na, nb, _p(dl), _p(dr), stream_ptr()), "ldt_chamfer")
+    return dl, dr

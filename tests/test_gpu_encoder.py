@@ -1,0 +1,146 @@
+"""GPU (-m gpu): Compressor encoder front end (FPS, kNN, grouping) and Compressor.forward vs oracle / golden.
+
+Index work is exact (FPS index sequence; kNN index sets up to exact-distance ties at the k-th neighbour, which
+are compared through their sorted distances).  Floating-point outputs: the bf16 tolerances of test_gpu_path.py."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_mse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from ldt_amd import ops
+    from oracle import ldt_oracle as O
+    assert torch.cuda.is_available()
+    return ops, O
+
+
+def unit_clouds(B, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(B, n, 3, generator=g)
+    p = p - p.mean(1, keepdim=True)
+    return p / p.norm(dim=-1).amax(1)[:, None, None]
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 2048, 256), (2, 2048, 32), (2, 64, 8), (1, 700, 33), (2, 5000, 40), (1, 8, 8)])
+def test_fps_exact(mods, B, n, m):
+    ops, O = mods
+    p = unit_clouds(B, n, n + m)
+    ref = O.fps(p, m)
+    out = ops.fps(p.cuda(), m)
+    assert out.dtype == torch.int32 and torch.equal(out.cpu().long(), ref)
+
+
+def test_fps_ties_and_start(mods):
+    ops, O = mods
+    p = torch.zeros(1, 600, 3)
+    p[0, 2] = torch.tensor([3., 0, 0]); p[0, 513] = torch.tensor([3., 0, 0])
+    assert ops.fps(p.cuda(), 2)[0].tolist() == [0, 513] == O.fps(p, 2)[0].tolist()
+    q = torch.tensor([[[0., 0, 0], [1, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 2, 0]]])
+    assert ops.fps(q.cuda(), 4)[0].tolist() == [0, 4, 1, 3]
+
+
+@pytest.mark.parametrize("B,n,S,k", [(2, 2048, 256, 16), (2, 2048, 32, 128), (2, 64, 8, 16), (1, 300, 7, 5), (1, 5000, 10, 64)])
+def test_knn_sets(mods, B, n, S, k):
+    ops, O = mods
+    p = unit_clouds(B, n, S * k)
+    cen = O.gather(p, O.fps(p, S))
+    ref_d = O.square_distance(cen, p)
+    ref_idx = torch.topk(ref_d, k, dim=-1, largest=False, sorted=False)[1]
+    idx, dist = ops.knn(p.cuda(), cen.cuda(), k, return_dist=True)
+    idx = idx.cpu().long()
+    assert float((dist.cpu() - ref_d).abs().max()) < 2e-6                     # same expanded-form distances
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    assert all(len(set(r.tolist())) == k for r in idx.reshape(-1, k))        # k distinct neighbours
+    got = torch.gather(ref_d, -1, idx).sort(-1)[0]
+    want = torch.gather(ref_d, -1, ref_idx).sort(-1)[0]
+    assert torch.allclose(got, want, rtol=1e-5, atol=2e-6)                    # same sets up to k-th-neighbour ties
+    same = (idx.sort(-1)[0] == ref_idx.sort(-1)[0]).all(-1).float().mean()
+    assert float(same) > 0.98
+
+
+def test_group_normalize_vs_oracle(mods):
+    ops, O = mods
+    B, n, D, S, k = 2, 256, 64, 16, 32
+    g = torch.Generator().manual_seed(4)
+    p = unit_clouds(B, n, 9)
+    feat = torch.randn(B, n, D, generator=g)
+    alpha = torch.rand(D + 3, generator=g) + 0.5; beta = torch.randn(D + 3, generator=g) * 0.2
+    fi = O.fps(p, S); ki = O.knn(k, p, O.gather(p, fi))
+    new_feat = O.gather(feat, fi)
+    grp = torch.cat([O.gather(feat, ki), O.gather(p, ki)], -1)
+    mean = torch.cat([new_feat, O.gather(p, fi)], -1).unsqueeze(-2)
+    std = torch.std((grp - mean).reshape(B, -1), dim=-1, keepdim=True)[..., None, None]
+    ref = torch.cat([alpha * ((grp - mean) / (std + 1e-5)) + beta, new_feat[:, :, None, :].expand(-1, -1, k, -1)], -1)
+    U = ops.group_normalize(feat.cuda(), p.cuda(), fi.int().cuda(), ki.int().cuda(), alpha.cuda(), beta.cuda())
+    assert U.shape == (B * S * k, 192)
+    assert rel_mse(U[:, :2 * D + 3].float().cpu(), ref.reshape(B * S * k, -1)) < 1e-5
+    assert float(U[:, 2 * D + 3:].float().abs().max()) == 0.0               # K padding is zero
+
+
+def test_small_ops(mods):
+    ops, O = mods
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(6 * 5, 40, generator=g)
+    assert torch.equal(ops.maxpool(x.cuda(), 6, 5).cpu(), x.view(6, 5, 40).max(1)[0])
+    xb = x.to(torch.bfloat16)
+    assert torch.equal(ops.maxpool(xb.cuda(), 6, 5).cpu(), xb.float().view(6, 5, 40).max(1)[0])
+    sh = torch.randn(5 * 40, generator=g); ls = torch.randn(5 * 40, generator=g) * 0.3
+    y = ops.actnorm_(x.clone().cuda(), sh.cuda(), ls.cuda(), 6)
+    assert rel_mse(y.cpu(), (x.view(6, 200) - sh) * torch.exp(-ls)) < 1e-12
+    post = torch.randn(30, 16, generator=g) * 20; nz = torch.randn(30, 8, generator=g)
+    out = torch.zeros(30, 24, device="cuda")
+    mu, lv = ops.reparam(post.cuda(), nz.cuda(), out[:, 8:16], -30., 10., want_stats=True)
+    lvr = post[:, 8:].clamp(-30., 10.)
+    assert rel_mse(out[:, 8:16].cpu(), post[:, :8] + torch.exp(lvr / 2.) * nz) < 1e-12
+    assert torch.equal(lv.cpu(), lvr) and torch.equal(mu.cpu(), post[:, :8]) and float(out[:, :8].abs().sum()) == 0
+    src = torch.randn(2, 9, 4, generator=g); idx = torch.tensor([[8, 0, 3], [1, 1, 7]], dtype=torch.int32)
+    assert torch.equal(ops.gather_rows(src.cuda(), idx.cuda()).cpu(), O.gather(src, idx.long()))
+
+
+def test_chamfer_golden(mods):
+    ops, O = mods
+    a, _ = load_golden("chamfer")
+    dl, dr = ops.chamfer(a["a"].cuda(), a["b"].cuda())
+    assert rel_mse(dl.cpu(), a["dl"]) < 1e-10 and rel_mse(dr.cpu(), a["dr"]) < 1e-10
+
+
+def test_compressor_forward_golden(tiny_cfg):
+    """Compressor.forward (encode + reconstruct) with the reference's recorded posterior noise."""
+    import ldt_amd
+    a, _ = load_golden("compressor_fwd_tiny")
+    _, csd = load_golden("trainer_sample_tiny")
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    comp.load_state_dict(csd["c"], strict=True)
+    comp = comp.cuda()
+    out = comp(a["pts"].cuda(), post_noise=list(a["post_noise"]), want_stats=True)
+    assert torch.equal(out["fps_idx"].cpu().long(), a["fps_idx"].long())
+    assert torch.equal(out["knn_idx"].cpu().long().sort(-1)[0], a["knn_idx"].long().sort(-1)[0])
+    assert rel_mse(out["tokens"].view(2, 8, -1).cpu(), a["tokens"]) < 1e-4
+    mu = torch.stack([p[1] for p in out["posteriors"]]); lv = torch.stack([p[2] for p in out["posteriors"]])
+    assert rel_mse(mu.cpu(), a["mu"]) < 1e-3 and rel_mse(lv.cpu(), a["logvar"]) < 1e-3
+    assert rel_mse(out["all_eps"].cpu(), a["all_eps"]) < 1e-3
+    assert rel_mse(out["set"].cpu(), a["set"]) < 1e-3
+    eps2 = comp.encode(a["pts"].cuda(), post_noise=list(a["post_noise"]))
+    assert torch.equal(eps2, out["all_eps"])
+
+
+def test_encode_decode_roundtrip_shapes_full_size():
+    """Shipped sizes (2048 points, 32 and 256 tokens): encode -> decode runs, finite, deterministic."""
+    import ldt_amd
+    for T in (32, 256):
+        cfg = ldt_amd.airplane_config(latent_tokens=T)
+        torch.manual_seed(1)
+        comp = ldt_amd.Compressor(cfg.compressor).cuda()
+        comp.init()
+        pts = unit_clouds(3, 2048, T).cuda()
+        torch.manual_seed(2); r1 = comp(pts)
+        torch.manual_seed(2); r2 = comp(pts)
+        assert r1["all_eps"].shape == (3, T, 120) and r1["set"].shape == (3, 2048, 3)
+        assert torch.isfinite(r1["all_eps"]).all() and torch.isfinite(r1["set"]).all()
+        assert torch.equal(r1["all_eps"], r2["all_eps"])
+        dec = comp.decode(r1["all_eps"], 2048)
+        assert rel_mse(dec.cpu(), r1["set"].cpu()) < 1e-6            # decode(all_eps) reproduces the reconstruction
