@@ -41,6 +41,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact-erf GELU (nn.GELU() default; model/layers.py:111-113 via tools/utils.py:107-108)
+// exact-erf GELU (nn.GELU() default; model/layers.py:111-113 via tools/utils.py:107-108).
+// gelu_erf: libm erff (fp32-accurate; used by the fp32 SGEMM path).
+// gelu_erf_fast: GEMM epilogue form whose output is rounded to bf16 anyway — erf by Abramowitz & Stegun 7.1.26
+// (|abs err| <= 1.5e-7, i.e. ~2^-13 of a bf16 ulp at |x|~1), branch-free: 1 rcp + 1 exp + 8 FMA instead of erff.
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(|x|/sqrt2)
+    const float phi = 0.5f * erfc_z;                                                    // Phi(-|x|)
+    return x * (x >= 0.f ? 1.0f - phi : phi);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

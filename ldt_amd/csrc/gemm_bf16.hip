@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
             } else {
                 if (EPI == EPI_GELU_BF16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
                 }
                 if (EPI == EPI_RELU_BF16) {
                     if (a.skip) {

@@ -90,7 +90,7 @@ def test_small_ops(mods):
     assert torch.equal(ops.maxpool(xb.cuda(), 6, 5).cpu(), xb.float().view(6, 5, 40).max(1)[0])
     sh = torch.randn(5 * 40, generator=g); ls = torch.randn(5 * 40, generator=g) * 0.3
     y = ops.actnorm_(x.clone().cuda(), sh.cuda(), ls.cuda(), 6)
-    assert rel_mse(y.cpu(), (x.view(6, 200) - sh) * torch.exp(-ls)) < 1e-12
+    assert rel_mse(y.cpu().view(6, 200), (x.view(6, 200) - sh) * torch.exp(-ls)) < 1e-12
     post = torch.randn(30, 16, generator=g) * 20; nz = torch.randn(30, 8, generator=g)
     out = torch.zeros(30, 24, device="cuda")
     mu, lv = ops.reparam(post.cuda(), nz.cuda(), out[:, 8:16], -30., 10., want_stats=True)
