@@ -20,6 +20,8 @@
 //   EPI_GELU_BF16  out bf16  = gelu_erf(acc + bias)                       (MLP up, layers.py:127-129)
 //   EPI_RELU_BF16  out bf16  = relu(acc + bias [+ skip bf16])             (PreExtraction, Compressor/layers.py:115-160)
 //   EPI_RESID_F32  out fp32  = resid + gate[s,n] * (acc + bias)           (x + gate*(...), layers.py:218-219; gate may be null)
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define BM 128
@@ -172,6 +174,223 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     }
 }
 
+
+// =================================================================================================
+// v2: 256x256 tile, 8 waves in two groups that ping-pong on each SIMD (CDNA4 guide "8-phase" structure).
+//
+//   * 512 threads = 8 waves; wave w and w+4 share a SIMD.  Group g = w>>2 owns output rows [g*128, +128) of the
+//     tile, wn = w&3 owns 64 output columns: per wave 128x64 = 8x4 accumulator tiles of mfma_f32_16x16x32_bf16
+//     (operands swapped as in v1: D[n][m]).
+//   * K is consumed in 32-deep sub-tiles through a 4-slot LDS ring (slot = X[256][32] + W[256][32] bf16 = 32 KiB;
+//     128 KiB total, one workgroup per CU).  Rows are 64 B; the 16-B chunk index is XORed with f((row>>2)&3),
+//     f = {0,2,3,1}, which makes every ds_read_b128 lane group of the 16x16x32 operand read conflict-free
+//     (applied on the glds SOURCE address and on the read address).
+//   * Each sub-tile is two phases of 16 MFMAs.  A phase = [load segment: ds_reads of this phase's operands +
+//     one glds batch (2 x 1 KiB per wave) for a future sub-tile] s_barrier [16 MFMAs] s_barrier.  Group 1 runs
+//     one barrier behind group 0, so on every SIMD one wave issues MFMAs while its partner reads LDS / issues DMA.
+//   * glds for sub-tile v: X at phase 1 of sub-tile v-3, W at phase 0 of sub-tile v-2; the only VMEM wait in the
+//     loop is a counted `s_waitcnt vmcnt(6)` once per sub-tile (three batches stay in flight across barriers).
+//     Slot reuse distance >= 2 phases after the last read (WAR), data is read >= 1 barrier after every wave's
+//     counted wait (RAW).  Past the end of K the batches are still issued (clamped to the last sub-tile, never
+//     consumed) so the wait count stays uniform.
+#define V2_STAGE_BYTES 32768
+#define V2_OPER_BYTES 16384
+
+__device__ __forceinline__ int v2_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+__device__ __forceinline__ void v2_stage(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total, int k0,
+                                         char* lds_oper, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int piece = wave * 2 + p;                       // 16 pieces of 16 rows x 64 B
+        const int r = piece * 16 + (lane >> 2);
+        const int csrc = (lane & 3) ^ v2_swz(r);
+        int grow = row0 + r;
+        grow = grow < nrows_total ? grow : nrows_total - 1;
+        const bf16_t* src = g + (long)grow * ld + k0 + csrc * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_oper + piece * 1024), 16, 0, 0);
+    }
+}
+
+#define V2_BARRIER()                          \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
+template <int EPI, bool INTERIOR>
+__device__ __forceinline__ void v2_epilogue(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
+                                            int lrow, int lchk, const float* gate) {
+    // lane holds D[n = nb + lchk*4 + r][m = mb + lrow]
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + grp * 128 + mi * 16 + lrow;
+        if (!INTERIOR && m >= a.M) continue;
+        const float* grow = nullptr;
+        if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + lchk * 4;
+            if (!INTERIOR && n >= a.N) continue;
+            f32x4 v = acc[ni][mi];
+            const bool full = INTERIOR || (n + 3 < a.N);
+            if (a.bias) {
+                if (full) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += t[r]; }
+                else for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += a.bias[n + r];
+            }
+            if (EPI == EPI_F32) {
+                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
+                if (full) *reinterpret_cast<f32x4*>(o) = v;
+                else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
+            } else if (EPI == EPI_RESID_F32) {
+                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
+                const float* rs = a.resid + (long)m * a.ldr + n;
+                if (full) {
+                    f32x4 x = *reinterpret_cast<const f32x4*>(rs);
+                    if (grow) { const f32x4 g = *reinterpret_cast<const f32x4*>(grow + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = x[r] + g[r] * v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] = x[r] + v[r];
+                    }
+                    *reinterpret_cast<f32x4*>(o) = x;
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = rs[r] + (grow ? grow[n + r] : 1.f) * v[r];
+                }
+            } else {
+                if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                }
+                if (EPI == EPI_RELU_BF16) {
+                    if (a.skip) {
+                        const bf16_t* sk = a.skip + (long)m * a.lds_ + n;
+                        for (int r = 0; r < 4; ++r) if (full || n + r < a.N) v[r] += (float)sk[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)m * a.ldo + n;
+                if (full) {
+                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(o) = pk;
+                } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+
+    const int tiles_n = (a.N + 255) / 256;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int m0 = (wgid / tiles_n) * 256, n0 = (wgid % tiles_n) * 256;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nks = a.K >> 5;
+    const int lrow = lane & 15, lchk = lane >> 4;
+
+#define ISSUE_X(v_) do { const int vv_ = (v_) < nks ? (v_) : nks - 1; \
+        v2_stage(a.X, a.ldx, m0, a.M, vv_ << 5, smem2 + ((v_) & 3) * V2_STAGE_BYTES, wave, lane); } while (0)
+#define ISSUE_W(v_) do { const int vv_ = (v_) < nks ? (v_) : nks - 1; \
+        v2_stage(a.W, a.ldw, n0, a.N, vv_ << 5, smem2 + ((v_) & 3) * V2_STAGE_BYTES + V2_OPER_BYTES, wave, lane); } while (0)
+
+    ISSUE_X(0); ISSUE_W(0); ISSUE_X(1); ISSUE_W(1); ISSUE_X(2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    V2_BARRIER();
+    if (grp == 1) V2_BARRIER();                               // stagger the two groups by one barrier
+
+    // per-lane LDS read offsets inside an operand sub-tile: row*64 + ((chunk ^ f(row)) << 4)
+    int xoff[8], woff[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int r = grp * 128 + i * 16 + lrow; xoff[i] = r * 64 + ((lchk ^ v2_swz(r)) << 4); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + lrow; woff[i] = V2_OPER_BYTES + r * 64 + ((lchk ^ v2_swz(r)) << 4); }
+
+    for (int v = 0; v < nks; ++v) {
+        const char* st = smem2 + (v & 3) * V2_STAGE_BYTES;
+        bf16x8 wf[4], xf[4];
+        // ---------------- phase 0: W(all 4 n-tiles) + X(m-tiles 0..3) ----------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + woff[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
+        ISSUE_W(v + 2);
+        V2_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        V2_BARRIER();
+        // ---------------- phase 1: X(m-tiles 4..7) ----------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
+        ISSUE_X(v + 3);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // sub-tile v+1 has landed (3 newer batches in flight)
+        V2_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        V2_BARRIER();
+    }
+    if (grp == 0) V2_BARRIER();                               // every wave executes the same number of barriers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the (unused) tail batches before exit
+#undef ISSUE_X
+#undef ISSUE_W
+
+    const float* gate = a.gate;
+    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+    if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N)) v2_epilogue<EPI, true>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
+    else v2_epilogue<EPI, false>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
+}
+
+template <int EPI>
+static int launch_256(const GemmArgs* a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 * V2_STAGE_BYTES);
+        if (e != hipSuccess) { ldt_set_error("gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles), dim3(512), 4 * V2_STAGE_BYTES, stream, *a);
+    return ldt_check_launch("gemm_bf16_nt_256");
+}
+
+// LDT_GEMM_FORCE=128|256 pins the variant (A/B runs); default: 256^2 when it fills at least half the CUs.
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LDT_GEMM_FORCE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, LDT_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     LDT_REQUIRE(a->K % BK == 0, LDT_ESHAPE, "gemm: K=%d must be a multiple of %d (pad activations/weights)", a->K, BK);
@@ -185,6 +404,18 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
                     LDT_EARG, "gemm: gate needs rows_per_sample>0 and 16-byte aligned strides");
     }
     LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm: bias must be 16-byte aligned");
+    const int tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const int force = gemm_variant();
+    if ((force == 256 || (force == 0 && tiles256 >= 128)) && a->M >= 16 && a->N >= 16) {
+        switch (epi) {
+            case EPI_F32: return launch_256<EPI_F32>(a, stream);
+            case EPI_BF16: return launch_256<EPI_BF16>(a, stream);
+            case EPI_GELU_BF16: return launch_256<EPI_GELU_BF16>(a, stream);
+            case EPI_RELU_BF16: return launch_256<EPI_RELU_BF16>(a, stream);
+            case EPI_RESID_F32: return launch_256<EPI_RESID_F32>(a, stream);
+            default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
+        }
+    }
     const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     dim3 grid(tiles), block(256);
     switch (epi) {
