@@ -193,6 +193,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
 //     Slot reuse distance >= 2 phases after the last read (WAR), data is read >= 1 barrier after every wave's
 //     counted wait (RAW).  Past the end of K the batches are still issued (clamped to the last sub-tile, never
 //     consumed) so the wait count stays uniform.
+#ifndef V2_STAGED_EPILOGUE
+#define V2_STAGED_EPILOGUE 1
+#endif
+#ifndef V2_ORDER
+#define V2_ORDER 0
+#endif
+#ifndef V2_ABLATE
+#define V2_ABLATE 0          // timing-only ablations for tools/dbg (1: no glds in the loop, 2: no ds_reads, 4: no barriers)
+#endif
 #define V2_STAGE_BYTES 32768
 #define V2_OPER_BYTES 16384
 
@@ -203,8 +212,13 @@ __device__ __forceinline__ void v2_stage(const bf16_t* __restrict__ g, long ld, 
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int piece = wave * 2 + p;                       // 16 pieces of 16 rows x 64 B
+#if V2_ABLATE & 8
+        const int r = piece * 8 + (lane >> 3);                // timing-only: full 128-B lines (wrong data)
+        const int csrc = (lane & 7);
+#else
         const int r = piece * 16 + (lane >> 2);
         const int csrc = (lane & 3) ^ v2_swz(r);
+#endif
         int grow = row0 + r;
         grow = grow < nrows_total ? grow : nrows_total - 1;
         const bf16_t* src = g + (long)grow * ld + k0 + csrc * 8;
@@ -213,12 +227,16 @@ __device__ __forceinline__ void v2_stage(const bf16_t* __restrict__ g, long ld, 
     }
 }
 
+#if V2_ABLATE & 4
+#define V2_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
 #define V2_BARRIER()                          \
     do {                                      \
         __builtin_amdgcn_sched_barrier(0);    \
         __builtin_amdgcn_s_barrier();         \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
+#endif
 
 template <int EPI, bool INTERIOR>
 __device__ __forceinline__ void v2_epilogue(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
@@ -242,7 +260,9 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& a, f32x4 (&acc)[4][8
                     for (int r = 0; r < 4; ++r) v[r] += t[r]; }
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += a.bias[n + r];
             }
-            if (EPI == EPI_F32) {
+            if (EPI == 5) {                     // timing-only: keep the accumulators live, store nothing
+                if (a.M < 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n) = v;
+            } else if (EPI == EPI_F32) {
                 float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
                 if (full) *reinterpret_cast<f32x4*>(o) = v;
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
@@ -280,6 +300,99 @@ __device__ __forceinline__ void v2_epilogue(const GemmArgs& a, f32x4 (&acc)[4][8
                     bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                     *reinterpret_cast<bf16x4*>(o) = pk;
                 } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
+            }
+        }
+    }
+}
+
+// Interior-tile epilogue staged through the (now idle) LDS ring so that every global access is 16 B per lane
+// over whole output rows: the MFMA fragment layout gives each lane 4 consecutive columns of 16 DIFFERENT rows,
+// i.e. 32-B (bf16) / 64-B (fp32) row pieces per store instruction, which is store-ISSUE bound (guide T21).
+// Each wave owns a private LDS region (no workgroup barrier): it writes its accumulator fragments row-major
+// (row stride padded by 16 B against bank conflicts), reads rows back as 16-B chunks and streams them out:
+//   bf16 out : 2 passes of 64 rows x 128 B  -> one store instruction = 8 rows x 128 B
+//   fp32 out : 4 passes of 32 rows x 256 B  -> one access            = 4 rows x 256 B  (+ residual read, gate)
+template <int EPI>
+__device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
+                                                   int wave, int lane, int lrow, int lchk, const float* gate, char* smem) {
+    const int mb = m0 + grp * 128, nb = n0 + wn * 64;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+        bias4[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
+        constexpr int RS = 128 + 16;                              // bytes per staged row
+        char* reg = smem + wave * (64 * RS);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = mi * 16 + lrow;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = acc[ni][half * 4 + mi];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                    if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                    }
+                    if (EPI == EPI_RELU_BF16) {
+                        if (a.skip) {
+                            const bf16x4 sk = *reinterpret_cast<const bf16x4*>(a.skip + (long)(mb + half * 64 + row) * a.lds_ + nb + ni * 16 + lchk * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)sk[r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(reg + row * RS + (ni * 16 + lchk * 4) * 2) = pk;
+                }
+            }
+            bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)(mb + half * 64) * a.ldo + nb;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(reg + row * RS + ch * 16);
+                *reinterpret_cast<bf16x8*>(o + (long)row * a.ldo + ch * 8) = d;
+            }
+        }
+    } else {
+        constexpr int RS = 256 + 16;
+        char* reg = smem + wave * (32 * RS);
+        const int ch = lane & 15;
+        f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
+        const bool has_gate = (EPI == EPI_RESID_F32) && gate;
+        const bool shared_gate = has_gate && a.gate_sample_stride == 0;
+        if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = mi * 16 + lrow;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = acc[ni][qd * 2 + mi];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                    *reinterpret_cast<f32x4*>(reg + row * RS + (ni * 16 + lchk * 4) * 4) = v;
+                }
+            }
+            const long mrow0 = mb + qd * 32;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * RS + ch * 16);
+                float* o = reinterpret_cast<float*>(a.out) + (mrow0 + row) * a.ldo + nb + ch * 4;
+                if (EPI == EPI_RESID_F32) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(a.resid + (mrow0 + row) * a.ldr + nb + ch * 4);
+                    if (has_gate && !shared_gate)
+                        g4 = *reinterpret_cast<const f32x4*>(gate + ((mrow0 + row) / a.rows_per_sample) * a.gate_sample_stride + nb + ch * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
+                }
+                if (EPI != 5 || a.M < 0) *reinterpret_cast<f32x4*>(o) = v;
             }
         }
     }
@@ -326,15 +439,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + lrow; woff[i] = V2_OPER_BYTES + r * 64 + ((lchk ^ v2_swz(r)) << 4); }
 
+#if V2_ABLATE & 2
+    bf16x8 wf[4], xf[4];
+    for (int i = 0; i < 4; ++i) { wf[i] = *reinterpret_cast<const bf16x8*>(smem2 + woff[i]); xf[i] = *reinterpret_cast<const bf16x8*>(smem2 + xoff[i]); }
+#endif
     for (int v = 0; v < nks; ++v) {
         const char* st = smem2 + (v & 3) * V2_STAGE_BYTES;
+#if !(V2_ABLATE & 2)
         bf16x8 wf[4], xf[4];
+#endif
         // ---------------- phase 0: W(all 4 n-tiles) + X(m-tiles 0..3) ----------------
+#if V2_ORDER == 1 && !(V2_ABLATE & 1)
+        ISSUE_W(v + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(V2_ABLATE & 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + woff[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
+#else
+        asm volatile("" : "+v"(wf[0]), "+v"(xf[0]) :: "memory"); (void)st;
+#endif
+#if V2_ORDER == 0 && !(V2_ABLATE & 1)
         ISSUE_W(v + 2);
+#endif
         V2_BARRIER();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -345,10 +474,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
         __builtin_amdgcn_s_setprio(0);
         V2_BARRIER();
         // ---------------- phase 1: X(m-tiles 4..7) ----------------
+#if V2_ORDER == 1 && !(V2_ABLATE & 1)
+        ISSUE_X(v + 3);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(V2_ABLATE & 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
+#endif
+#if !(V2_ABLATE & 1)
+#if V2_ORDER == 0
         ISSUE_X(v + 3);
+#endif
+#if !(V2_ABLATE & 16)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // sub-tile v+1 has landed (3 newer batches in flight)
+#endif
+#endif
         V2_BARRIER();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -360,13 +501,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
         V2_BARRIER();
     }
     if (grp == 0) V2_BARRIER();                               // every wave executes the same number of barriers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the (unused) tail batches before exit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the (unused) tail batches ...
+    V2_BARRIER();                                             // ... of EVERY wave: the ring is quiescent, LDS is reusable
 #undef ISSUE_X
 #undef ISSUE_W
 
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
-    if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N)) v2_epilogue<EPI, true>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
+    const bool aligned = (a.ldo % 8 == 0) && (EPI != EPI_RESID_F32 || a.ldr % 4 == 0) && (EPI != EPI_RELU_BF16 || !a.skip || a.lds_ % 4 == 0);
+    if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned && V2_STAGED_EPILOGUE)
+        v2_epilogue_staged<EPI>(a, acc, m0, n0, grp, wn, wave, lane, lrow, lchk, gate, smem2);
+    else if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N)) v2_epilogue<EPI, true>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
     else v2_epilogue<EPI, false>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
 }
 
@@ -413,6 +558,7 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
             case EPI_GELU_BF16: return launch_256<EPI_GELU_BF16>(a, stream);
             case EPI_RELU_BF16: return launch_256<EPI_RELU_BF16>(a, stream);
             case EPI_RESID_F32: return launch_256<EPI_RESID_F32>(a, stream);
+            case 5: return launch_256<5>(a, stream);       // timing-only (tools/dbg): no stores
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }
     }
