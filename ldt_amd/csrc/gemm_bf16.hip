@@ -176,214 +176,164 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
 
 
 // =================================================================================================
-// v2: 256x256 tile, 8 waves in two groups that ping-pong on each SIMD (CDNA4 guide "8-phase" structure).
+// v2: persistent 256x256-tile kernel, 8 waves in two groups that ping-pong on each SIMD (the CDNA4 guide's
+// "8-phase" structure), one workgroup per CU, K streamed continuously ACROSS output tiles.
 //
 //   * 512 threads = 8 waves; wave w and w+4 share a SIMD.  Group g = w>>2 owns output rows [g*128, +128) of the
 //     tile, wn = w&3 owns 64 output columns: per wave 128x64 = 8x4 accumulator tiles of mfma_f32_16x16x32_bf16
 //     (operands swapped as in v1: D[n][m]).
-//   * K is consumed in 32-deep sub-tiles through a 4-slot LDS ring (slot = X[256][32] + W[256][32] bf16 = 32 KiB;
-//     128 KiB total, one workgroup per CU).  Rows are 64 B; the 16-B chunk index is XORed with f((row>>2)&3),
-//     f = {0,2,3,1}, which makes every ds_read_b128 lane group of the 16x16x32 operand read conflict-free
-//     (applied on the glds SOURCE address and on the read address).
-//   * Each sub-tile is two phases of 16 MFMAs.  A phase = [load segment: ds_reads of this phase's operands +
-//     one glds batch (2 x 1 KiB per wave) for a future sub-tile] s_barrier [16 MFMAs] s_barrier.  Group 1 runs
-//     one barrier behind group 0, so on every SIMD one wave issues MFMAs while its partner reads LDS / issues DMA.
-//   * glds for sub-tile v: X at phase 1 of sub-tile v-3, W at phase 0 of sub-tile v-2; the only VMEM wait in the
-//     loop is a counted `s_waitcnt vmcnt(6)` once per sub-tile (three batches stay in flight across barriers).
-//     Slot reuse distance >= 2 phases after the last read (WAR), data is read >= 1 barrier after every wave's
-//     counted wait (RAW).  Past the end of K the batches are still issued (clamped to the last sub-tile, never
-//     consumed) so the wait count stays uniform.
-#ifndef V2_STAGED_EPILOGUE
-#define V2_STAGED_EPILOGUE 1
-#endif
-#ifndef V2_ORDER
-#define V2_ORDER 0
-#endif
-#ifndef V2_ABLATE
-#define V2_ABLATE 0          // timing-only ablations for tools/dbg (1: no glds in the loop, 2: no ds_reads, 4: no barriers)
+//   * K is consumed in 32-deep sub-tiles through a 4-slot LDS ring (slot = X[256][32] + W[256][32] bf16 = 32 KiB).
+//     Rows are 64 B; the 16-B chunk index is XORed with f((row>>2)&3), f = {0,2,3,1}: every ds_read_b128 lane
+//     group of the 16x16x32 operand read is bank-conflict-free (applied on the glds SOURCE address + read address).
+//   * Each sub-tile is two phases of 16 MFMAs.  A phase = [load segment: ds_reads of this phase's operands + one
+//     glds batch (2 x 1 KiB per wave) for a future sub-tile] s_barrier [16 MFMAs] s_barrier.  Group 1 runs one
+//     barrier behind group 0, so on every SIMD one wave issues MFMAs while its partner reads LDS / issues DMA.
+//   * The sub-tile stream does not stop at a tile boundary: the W batch issued at phase 0 of stream position g is
+//     for position g+2, the X batch at phase 1 for g+3 — possibly the first sub-tiles of this workgroup's NEXT
+//     tile, so the next tile's operands are already in LDS when the epilogue ends (no prologue bubble).  The only
+//     VMEM wait in the loop is a counted `s_waitcnt vmcnt(6)` once per sub-tile (three batches stay in flight);
+//     the first wait after an epilogue allows for the epilogue's own stores (vmcnt counts stores, in order).
+//     Slot reuse distance >= 2 phases after the last read (WAR); data is read >= 1 barrier after every wave's
+//     counted wait (RAW).  Past the end of the stream the batches are still issued (clamped, never consumed).
+//   * Epilogue: accumulators -> per-wave 4 KiB LDS staging area (beside the ring, 160 KiB LDS in total) -> 16-B
+//     per lane accesses over whole output rows (the raw fragment layout is store-issue bound, guide T21); stores
+//     are not waited for, they drain under the next tile's main loop.
+#ifndef V2_NEXT_IN_L
+#define V2_NEXT_IN_L 1
 #endif
 #define V2_STAGE_BYTES 32768
 #define V2_OPER_BYTES 16384
+#define V2_RING_BYTES (4 * V2_STAGE_BYTES)
+#define V2_LDS_BYTES (V2_RING_BYTES + 8 * 4096)
 
 __device__ __forceinline__ int v2_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-__device__ __forceinline__ void v2_stage(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total, int k0,
-                                         char* lds_oper, int wave, int lane) {
+// Per-lane DMA source pointers of one operand stream: 2 pieces (16 rows x 64 B each) per wave and sub-tile.
+struct V2Stream {
+    const bf16_t* p[2];     // this lane's 16-B source of piece 0 / 1 at the stream's current (tile, sub-tile)
+    int it, v, inc;         // tile iteration; sub-tiles left in that tile; elements per advance (0 once parked)
+};
+__device__ __forceinline__ void v2_stream_seek(V2Stream& st, const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
+                                               int k0, int wave, int lane) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int piece = wave * 2 + p;                       // 16 pieces of 16 rows x 64 B
-#if V2_ABLATE & 8
-        const int r = piece * 8 + (lane >> 3);                // timing-only: full 128-B lines (wrong data)
-        const int csrc = (lane & 7);
-#else
-        const int r = piece * 16 + (lane >> 2);
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wave * 2 + q) * 16 + (lane >> 2);
         const int csrc = (lane & 3) ^ v2_swz(r);
-#endif
         int grow = row0 + r;
-        grow = grow < nrows_total ? grow : nrows_total - 1;
-        const bf16_t* src = g + (long)grow * ld + k0 + csrc * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds_oper + piece * 1024), 16, 0, 0);
+        grow = grow < nrows_total ? grow : nrows_total - 1;   // clamp: rows past the edge are never stored
+        st.p[q] = g + (long)grow * ld + k0 + csrc * 8;
     }
 }
+__device__ __forceinline__ void v2_stream_issue(const V2Stream& st, char* lds_oper, int wave) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)st.p[q],
+                                         (__attribute__((address_space(3))) void*)(lds_oper + (wave * 2 + q) * 1024), 16, 0, 0);
+}
 
-#if V2_ABLATE & 4
-#define V2_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
 #define V2_BARRIER()                          \
     do {                                      \
         __builtin_amdgcn_sched_barrier(0);    \
         __builtin_amdgcn_s_barrier();         \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
-#endif
 
-template <int EPI, bool INTERIOR>
-__device__ __forceinline__ void v2_epilogue(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
-                                            int lrow, int lchk, const float* gate) {
-    // lane holds D[n = nb + lchk*4 + r][m = mb + lrow]
+// generic (edge-safe) epilogue straight from the fragment layout: lane holds D[n = nb + lchk*4 + r][m = mb + lrow]
+template <int EPI>
+__device__ __forceinline__ void v2_epilogue_edge(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
+                                                 int lrow, int lchk, const float* gate) {
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int m = m0 + grp * 128 + mi * 16 + lrow;
-        if (!INTERIOR && m >= a.M) continue;
+        if (m >= a.M) continue;
         const float* grow = nullptr;
         if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + lchk * 4;
-            if (!INTERIOR && n >= a.N) continue;
+            if (n >= a.N) continue;
             f32x4 v = acc[ni][mi];
-            const bool full = INTERIOR || (n + 3 < a.N);
-            if (a.bias) {
-                if (full) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += t[r]; }
-                else for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += a.bias[n + r];
-            }
-            if (EPI == 5) {                     // timing-only: keep the accumulators live, store nothing
-                if (a.M < 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n) = v;
-            } else if (EPI == EPI_F32) {
-                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
-                if (full) *reinterpret_cast<f32x4*>(o) = v;
-                else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
-            } else if (EPI == EPI_RESID_F32) {
-                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
-                const float* rs = a.resid + (long)m * a.ldr + n;
-                if (full) {
-                    f32x4 x = *reinterpret_cast<const f32x4*>(rs);
-                    if (grow) { const f32x4 g = *reinterpret_cast<const f32x4*>(grow + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) x[r] = x[r] + g[r] * v[r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) x[r] = x[r] + v[r];
-                    }
-                    *reinterpret_cast<f32x4*>(o) = x;
-                } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = rs[r] + (grow ? grow[n + r] : 1.f) * v[r];
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= a.N) continue;
+                float y = v[r] + (a.bias ? a.bias[n + r] : 0.f);
+                const long oi = (long)m * a.ldo + n + r;
+                if (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[oi] = y;
+                else if (EPI == EPI_RESID_F32)
+                    reinterpret_cast<float*>(a.out)[oi] = a.resid[(long)m * a.ldr + n + r] + (grow ? grow[n + r] : 1.f) * y;
+                else if (EPI == EPI_DISCARD) { if (a.M < 0) reinterpret_cast<float*>(a.out)[oi] = y; }
+                else {
+                    if (EPI == EPI_GELU_BF16) y = gelu_erf_fast(y);
+                    if (EPI == EPI_RELU_BF16) { if (a.skip) y += (float)a.skip[(long)m * a.lds_ + n + r]; y = fmaxf(y, 0.f); }
+                    reinterpret_cast<bf16_t*>(a.out)[oi] = (bf16_t)y;
                 }
-            } else {
-                if (EPI == EPI_GELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
-                }
-                if (EPI == EPI_RELU_BF16) {
-                    if (a.skip) {
-                        const bf16_t* sk = a.skip + (long)m * a.lds_ + n;
-                        for (int r = 0; r < 4; ++r) if (full || n + r < a.N) v[r] += (float)sk[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)m * a.ldo + n;
-                if (full) {
-                    bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    *reinterpret_cast<bf16x4*>(o) = pk;
-                } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
             }
         }
     }
 }
 
-// Interior-tile epilogue staged through the (now idle) LDS ring so that every global access is 16 B per lane
-// over whole output rows: the MFMA fragment layout gives each lane 4 consecutive columns of 16 DIFFERENT rows,
-// i.e. 32-B (bf16) / 64-B (fp32) row pieces per store instruction, which is store-ISSUE bound (guide T21).
-// Each wave owns a private LDS region (no workgroup barrier): it writes its accumulator fragments row-major
-// (row stride padded by 16 B against bank conflicts), reads rows back as 16-B chunks and streams them out:
-//   bf16 out : 2 passes of 64 rows x 128 B  -> one store instruction = 8 rows x 128 B
-//   fp32 out : 4 passes of 32 rows x 256 B  -> one access            = 4 rows x 256 B  (+ residual read, gate)
+// interior tiles: per-wave LDS staging (16 output rows per pass) -> 16 B per lane over whole rows
 template <int EPI>
 __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
-                                                   int wave, int lane, int lrow, int lchk, const float* gate, char* smem) {
+                                                   int lane, int lrow, int lchk, const float* gate, char* reg) {
     const int mb = m0 + grp * 128, nb = n0 + wn * 64;
     f32x4 bias4[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
         bias4[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
-        constexpr int RS = 128 + 16;                              // bytes per staged row
-        char* reg = smem + wave * (64 * RS);
+        constexpr int RS = 128 + 16;                              // staged row: 64 bf16 + 16 B pad
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = mi * 16 + lrow;
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[ni][mi];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    f32x4 v = acc[ni][half * 4 + mi];
+                for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                if (EPI == EPI_GELU_BF16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
-                    if (EPI == EPI_GELU_BF16) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
-                    }
-                    if (EPI == EPI_RELU_BF16) {
-                        if (a.skip) {
-                            const bf16x4 sk = *reinterpret_cast<const bf16x4*>(a.skip + (long)(mb + half * 64 + row) * a.lds_ + nb + ni * 16 + lchk * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)sk[r];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    *reinterpret_cast<bf16x4*>(reg + row * RS + (ni * 16 + lchk * 4) * 2) = pk;
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
                 }
-            }
-            bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)(mb + half * 64) * a.ldo + nb;
+                if (EPI == EPI_RELU_BF16) {
+                    if (a.skip) {
+                        const bf16x4 sk = *reinterpret_cast<const bf16x4*>(a.skip + (long)(mb + mi * 16 + lrow) * a.lds_ + nb + ni * 16 + lchk * 4);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+                        for (int r = 0; r < 4; ++r) v[r] += (float)sk[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(reg + lrow * RS + (ni * 16 + lchk * 4) * 2) = pk;
+            }
+            bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (long)(mb + mi * 16) * a.ldo + nb;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
                 const int row = it * 8 + (lane >> 3), ch = lane & 7;
                 const bf16x8 d = *reinterpret_cast<const bf16x8*>(reg + row * RS + ch * 16);
                 *reinterpret_cast<bf16x8*>(o + (long)row * a.ldo + ch * 8) = d;
             }
         }
     } else {
-        constexpr int RS = 256 + 16;
-        char* reg = smem + wave * (32 * RS);
-        const int ch = lane & 15;
+        const int ch = lane & 15;                                 // 16-B chunk of the 256-B fp32 row (XOR-swizzled by row)
         f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
         const bool has_gate = (EPI == EPI_RESID_F32) && gate;
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
         if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
+        for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int row = mi * 16 + lrow;
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 v = acc[ni][mi];
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    f32x4 v = acc[ni][qd * 2 + mi];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
-                    *reinterpret_cast<f32x4*>(reg + row * RS + (ni * 16 + lchk * 4) * 4) = v;
-                }
+                for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                *reinterpret_cast<f32x4*>(reg + lrow * 256 + (((ni * 4 + lchk) ^ lrow) << 4)) = v;
             }
-            const long mrow0 = mb + qd * 32;
+            const long mrow0 = mb + mi * 16;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + (lane >> 4);
-                f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * RS + ch * 16);
+                f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((ch ^ row) << 4));
                 float* o = reinterpret_cast<float*>(a.out) + (mrow0 + row) * a.ldo + nb + ch * 4;
                 if (EPI == EPI_RESID_F32) {
                     const f32x4 x = *reinterpret_cast<const f32x4*>(a.resid + (mrow0 + row) * a.ldr + nb + ch * 4);
@@ -392,7 +342,7 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                 }
-                if (EPI != 5 || a.M < 0) *reinterpret_cast<f32x4*>(o) = v;
+                if (EPI != EPI_DISCARD || a.M < 0) *reinterpret_cast<f32x4*>(o) = v;
             }
         }
     }
@@ -405,114 +355,145 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
-
-    const int tiles_n = (a.N + 255) / 256;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int m0 = (wgid / tiles_n) * 256, n0 = (wgid % tiles_n) * 256;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nks = a.K >> 5;
     const int lrow = lane & 15, lchk = lane >> 4;
+    const int nks = a.K >> 5;
 
-#define ISSUE_X(v_) do { const int vv_ = (v_) < nks ? (v_) : nks - 1; \
-        v2_stage(a.X, a.ldx, m0, a.M, vv_ << 5, smem2 + ((v_) & 3) * V2_STAGE_BYTES, wave, lane); } while (0)
-#define ISSUE_W(v_) do { const int vv_ = (v_) < nks ? (v_) : nks - 1; \
-        v2_stage(a.W, a.ldw, n0, a.N, vv_ << 5, smem2 + ((v_) & 3) * V2_STAGE_BYTES + V2_OPER_BYTES, wave, lane); } while (0)
+    // ---- this workgroup's tile list: the tiles are cut into 8 contiguous chunks (one per XCD label bid&7, so the
+    //      X row-panels an XCD's CUs share stay in its L2); inside a chunk workgroup j takes tiles j, j+wpx, ...
+    const int tiles_n = (a.N + 255) / 256;
+    const int tiles = ((a.M + 255) / 256) * tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int nx = G < 8 ? G : 8;                                        // XCD labels in use
+    const int xcd = bid % nx, j = bid / nx;
+    const int wpx = (G - xcd + nx - 1) / nx;                             // workgroups carrying this label
+    const int c_lo = (int)((long)tiles * xcd / nx), c_hi = (int)((long)tiles * (xcd + 1) / nx);
+    const int my_tiles = (c_hi - c_lo - j + wpx - 1) / wpx > 0 ? (c_hi - c_lo - j + wpx - 1) / wpx : 0;
+    if (my_tiles == 0) return;                                           // whole workgroup, before any barrier
 
-    ISSUE_X(0); ISSUE_W(0); ISSUE_X(1); ISSUE_W(1); ISSUE_X(2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    auto tile_of = [&](int it, int& m0, int& n0) {
+        const int id = c_lo + j + it * wpx;
+        m0 = (id / tiles_n) * 256; n0 = (id % tiles_n) * 256;
+    };
+    // Advance a stream by one sub-tile (called right after the MFMAs of a phase are issued): the common path is two
+    // pointer bumps.  At the end of this workgroup's stream it parks (inc = 0): later batches re-read the last
+    // sub-tile (valid memory), are counted by vmcnt like any other and are never consumed.
+    auto next_x = [&](V2Stream& st) {
+        const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
+        if (__builtin_expect(left != 0, 1)) { st.v = left; st.p[0] += st.inc; st.p[1] += st.inc; return; }
+        const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;        // once per tile
+        st.it = it;
+        if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.X, a.ldx, m0, a.M, 0, wave, lane); st.v = nks; }
+        else { st.v = 0x40000000; st.inc = 0; }
+    };
+    auto next_w = [&](V2Stream& st) {
+        const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
+        if (__builtin_expect(left != 0, 1)) { st.v = left; st.p[0] += st.inc; st.p[1] += st.inc; return; }
+        const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
+        st.it = it;
+        if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.W, a.ldw, n0, a.N, 0, wave, lane); st.v = nks; }
+        else { st.v = 0x40000000; st.inc = 0; }
+    };
+
+    V2Stream sx{{nullptr, nullptr}, 0, nks, 32}, sw{{nullptr, nullptr}, 0, nks, 32};
+    {
+        int m0, n0;
+        tile_of(0, m0, n0);
+        v2_stream_seek(sx, a.X, a.ldx, m0, a.M, 0, wave, lane);
+        v2_stream_seek(sw, a.W, a.ldw, n0, a.N, 0, wave, lane);
+    }
+    int gx = 0, gw = 0;                                                  // stream positions of the next X / W batch
+#define ISSUE_X() do { v2_stream_issue(sx, smem2 + (gx & 3) * V2_STAGE_BYTES, wave); ++gx; } while (0)
+#define ISSUE_W() do { v2_stream_issue(sw, smem2 + (gw & 3) * V2_STAGE_BYTES + V2_OPER_BYTES, wave); ++gw; } while (0)
+
+    ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx);   // X0 W0 X1 W1 X2
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     // sub-tile 0 landed
     V2_BARRIER();
-    if (grp == 1) V2_BARRIER();                               // stagger the two groups by one barrier
 
-    // per-lane LDS read offsets inside an operand sub-tile: row*64 + ((chunk ^ f(row)) << 4)
+    // per-lane LDS read offsets inside a ring slot: row*64 + ((chunk ^ f(row)) << 4)
     int xoff[8], woff[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { const int r = grp * 128 + i * 16 + lrow; xoff[i] = r * 64 + ((lchk ^ v2_swz(r)) << 4); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + lrow; woff[i] = V2_OPER_BYTES + r * 64 + ((lchk ^ v2_swz(r)) << 4); }
 
-#if V2_ABLATE & 2
-    bf16x8 wf[4], xf[4];
-    for (int i = 0; i < 4; ++i) { wf[i] = *reinterpret_cast<const bf16x8*>(smem2 + woff[i]); xf[i] = *reinterpret_cast<const bf16x8*>(smem2 + xoff[i]); }
-#endif
-    for (int v = 0; v < nks; ++v) {
-        const char* st = smem2 + (v & 3) * V2_STAGE_BYTES;
-#if !(V2_ABLATE & 2)
-        bf16x8 wf[4], xf[4];
-#endif
-        // ---------------- phase 0: W(all 4 n-tiles) + X(m-tiles 0..3) ----------------
-#if V2_ORDER == 1 && !(V2_ABLATE & 1)
-        ISSUE_W(v + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if !(V2_ABLATE & 2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + woff[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
-#else
-        asm volatile("" : "+v"(wf[0]), "+v"(xf[0]) :: "memory"); (void)st;
-#endif
-#if V2_ORDER == 0 && !(V2_ABLATE & 1)
-        ISSUE_W(v + 2);
-#endif
-        V2_BARRIER();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        V2_BARRIER();
-        // ---------------- phase 1: X(m-tiles 4..7) ----------------
-#if V2_ORDER == 1 && !(V2_ABLATE & 1)
-        ISSUE_X(v + 3);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#if !(V2_ABLATE & 2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
-#endif
-#if !(V2_ABLATE & 1)
-#if V2_ORDER == 0
-        ISSUE_X(v + 3);
-#endif
-#if !(V2_ABLATE & 16)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // sub-tile v+1 has landed (3 newer batches in flight)
-#endif
-#endif
-        V2_BARRIER();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        V2_BARRIER();
-    }
-    if (grp == 0) V2_BARRIER();                               // every wave executes the same number of barriers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the (unused) tail batches ...
-    V2_BARRIER();                                             // ... of EVERY wave: the ring is quiescent, LDS is reusable
-#undef ISSUE_X
-#undef ISSUE_W
-
+    // stores a wave leaves in flight after one STAGED epilogue (its loads are consumed, hence retired, inside it)
+    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16 : 32;
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
     const bool aligned = (a.ldo % 8 == 0) && (EPI != EPI_RESID_F32 || a.ldr % 4 == 0) && (EPI != EPI_RELU_BF16 || !a.skip || a.lds_ % 4 == 0);
-    if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned && V2_STAGED_EPILOGUE)
-        v2_epilogue_staged<EPI>(a, acc, m0, n0, grp, wn, wave, lane, lrow, lchk, gate, smem2);
-    else if ((m0 + 256 <= a.M) && (n0 + 256 <= a.N)) v2_epilogue<EPI, true>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
-    else v2_epilogue<EPI, false>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
+    char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
+
+    int g = 0;                                                           // stream position being consumed
+    bool prev_staged = false;
+    for (int it = 0; it < my_tiles; ++it) {
+        int m0, n0;
+        tile_of(it, m0, n0);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
+
+        for (int v = 0; v < nks; ++v, ++g) {
+            const char* st = smem2 + (g & 3) * V2_STAGE_BYTES;
+            bf16x8 wf[4], xf[4];
+            // ---------------- phase 0: W (4 n-tiles) + X (m-tiles 0..3); DMA: W of stream position g+2 ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + woff[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
+            ISSUE_W();
+#if V2_NEXT_IN_L
+            next_w(sw);
+#endif
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#if !V2_NEXT_IN_L
+            __builtin_amdgcn_sched_barrier(0);
+            next_w(sw);                                                  // address work for the next W batch, under the MFMAs
+#endif
+            V2_BARRIER();
+            // ---------------- phase 1: X (m-tiles 4..7); DMA: X of stream position g+3; counted wait ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
+            ISSUE_X();
+#if V2_NEXT_IN_L
+            next_x(sx);
+#endif
+            // position g+1 has landed once all but the 3 newest batches (+ a preceding epilogue's stores) retired
+            // (an edge epilogue issues a data-dependent number of stores: fall back to the always-safe vmcnt(6))
+            if (v == 0 && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + EPI_VMEM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+#if !V2_NEXT_IN_L
+            __builtin_amdgcn_sched_barrier(0);
+            next_x(sx);
+#endif
+            V2_BARRIER();
+        }
+        if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
+
+        prev_staged = (m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned;
+        if (prev_staged) v2_epilogue_staged<EPI>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg);
+        else v2_epilogue_edge<EPI>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail batches before exit
+#undef ISSUE_X
+#undef ISSUE_W
 }
 
 template <int EPI>
@@ -520,12 +501,13 @@ static int launch_256(const GemmArgs* a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 * V2_STAGE_BYTES);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
         if (e != hipSuccess) { ldt_set_error("gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(tiles), dim3(512), 4 * V2_STAGE_BYTES, stream, *a);
+    const int grid = tiles < LDT_NUM_CUS ? tiles : LDT_NUM_CUS;         // one persistent workgroup per CU
+    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256");
 }
 
@@ -558,7 +540,7 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
             case EPI_GELU_BF16: return launch_256<EPI_GELU_BF16>(a, stream);
             case EPI_RELU_BF16: return launch_256<EPI_RELU_BF16>(a, stream);
             case EPI_RESID_F32: return launch_256<EPI_RESID_F32>(a, stream);
-            case 5: return launch_256<5>(a, stream);       // timing-only (tools/dbg): no stores
+            case EPI_DISCARD: return launch_256<EPI_DISCARD>(a, stream);   // timing-only (tools/dbg): no stores
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }
     }

@@ -2,7 +2,9 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_F32 = 0, EPI_BF16 = 1, EPI_GELU_BF16 = 2, EPI_RELU_BF16 = 3, EPI_RESID_F32 = 4 };
+enum { EPI_F32 = 0, EPI_BF16 = 1, EPI_GELU_BF16 = 2, EPI_RELU_BF16 = 3, EPI_RESID_F32 = 4,
+       EPI_DISCARD = 5 /* timing-only: main loop without output stores (tools/dbg) */ };
+#define LDT_NUM_CUS 256      // MI355X
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GELU = 3 };
 
 struct GemmArgs {

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz,
     __shared__ float s_d[8];
     __shared__ int s_k[8];
     __shared__ float s_pt[3];
-    __shared__ int s_old;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = xyz + (long)b * n * 3;
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
@@ -71,7 +70,6 @@ __global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz,
         if (tid == 0) {
             float bd = s_d[0]; int bk = s_k[0];
             for (int w = 1; w < 8; ++w) if (beats(s_d[w], s_k[w], bd, bk)) { bd = s_d[w]; bk = s_k[w]; }
-            s_old = bk;
             idx_out[(long)b * m + it] = bk;
             s_pt[0] = p[3 * bk]; s_pt[1] = p[3 * bk + 1]; s_pt[2] = p[3 * bk + 2];
         }
