@@ -80,6 +80,17 @@ def score_flops_per_sample_step(cfg):
     return 2.0 * macs
 
 
+def measured_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes; gfx950: FETCH_SIZE doubled, units KiB — MI355X_MICROARCH.md §HBM).
+    None when no measurement of this kernel at this workload has been committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(symbol, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_pass(trainer, cfg, B, reps=3):
     """HIP-event timing of every launch of one Score forward (same stream), averaged over `reps` passes."""
     from ldt_amd import _lib, ops
@@ -116,17 +127,18 @@ def roofline_pass(trainer, cfg, B, reps=3):
             k["tflops"] = round(flops[name] / (avg * 1e-3) / 1e12, 2)
         kernels[name] = k
     dom = max(("gemm_qkv", "gemm_gelu", "gemm_resid"), key=lambda n: kernels[n]["ms_per_forward"])
-    sym = {"gemm_qkv": "gemm_bf16_nt_kernel<EPI_BF16>", "gemm_gelu": "gemm_bf16_nt_kernel<EPI_GELU_BF16>",
-           "gemm_resid": "gemm_bf16_nt_kernel<EPI_RESID_F32>"}[dom]
+    # symbols as rocprofv3 prints them (template argument = epilogue id: 1 BF16, 2 GELU_BF16, 4 RESID_F32)
+    sym = {"gemm_qkv": "gemm_bf16_nt_256_kernel<1>", "gemm_gelu": "gemm_bf16_nt_256_kernel<2>",
+           "gemm_resid": "gemm_bf16_nt_256_kernel<4>"}[dom]
     ach = kernels[dom]["tflops"]
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": sym,
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(sym), "kernel": sym,
             "flops_per_launch": flops[dom], "avg_launch_ms": kernels[dom]["avg_ms"]}
     a = kernels["attention"]
     abytes = 4.0 * M * D * 2                                               # read Q,K,V + write O in bf16
     gbs = abytes / (a["avg_ms"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "kernel": "attn_fwd_kernel<64>",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("attn_fwd_kernel<64>"), "kernel": "attn_fwd_kernel<64>",
             "bytes_per_launch": abytes, "avg_launch_ms": a["avg_ms"]}
     return roof, attn, kernels
 
