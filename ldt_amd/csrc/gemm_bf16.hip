@@ -24,17 +24,15 @@
 
 #include "kernels.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES (128 * BK * 2)      // 16 KiB per operand per stage
 
+template <int ROWS>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
                                            int k0, char* lds_tile, int wave, int lane) {
-    // one operand tile = 128 rows x 128 B = 16 pieces of 1 KiB (8 rows each); 4 pieces per wave
+    // one operand tile = ROWS rows x 128 B = ROWS/8 pieces of 1 KiB (8 rows each); ROWS/32 pieces per wave
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int piece = wave * 4 + p;
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int piece = wave * (ROWS / 32) + p;
         const int r = piece * 8 + (lane >> 3);
         const int cdst = lane & 7;
         const int csrc = cdst ^ ((r >> 1) & 7);
@@ -47,9 +45,14 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
     }
 }
 
-template <int EPI>
+// TBM x TBN output tile (each 128 or 64): 128x128 is the workhorse of mid-size problems, the smaller shapes keep all
+// 256 CUs busy when M*N is small (T=32 latents: M = 2048 rows).
+template <int EPI, int TBM, int TBN>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [stage][X|W]
+    constexpr int BM = TBM, BN = TBN;
+    constexpr int XB = TBM * BK * 2, WB = TBN * BK * 2;               // operand tile bytes per stage
+    constexpr int MT = TBM / 32, NT = TBN / 32;                       // 16x16 accumulator tiles per wave (m, n)
+    __shared__ __attribute__((aligned(16))) char smem[2 * (XB + WB)];  // [stage][X|W]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,15 +67,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / BK;
-    stage_tile(a.X, a.ldx, m0, a.M, 0, smem, wave, lane);
-    stage_tile(a.W, a.ldw, n0, a.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<TBM>(a.X, a.ldx, m0, a.M, 0, smem, wave, lane);
+    stage_tile<TBN>(a.W, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -80,28 +83,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const int lchk = lane >> 4;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        char* sx = smem + cur * 2 * TILE_BYTES;
-        char* sw = sx + TILE_BYTES;
+        char* sx = smem + cur * (XB + WB);
+        char* sw = sx + XB;
         if (kt + 1 < nk) {
-            char* nx = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nx, wave, lane);
-            stage_tile(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nx + TILE_BYTES, wave, lane);
+            char* nx = smem + (cur ^ 1) * (XB + WB);
+            stage_tile<TBM>(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nx, wave, lane);
+            stage_tile<TBN>(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nx + XB, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[4], xf[4];
+            bf16x8 wf[NT], xf[MT];
             const int c = ks * 4 + lchk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rw = wn * 64 + i * 16 + lrow;
+            for (int i = 0; i < NT; ++i) {
+                const int rw = wn * (TBN / 2) + i * 16 + lrow;
                 wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + ((c ^ ((rw >> 1) & 7)) << 4));
-                const int rx = wm * 64 + i * 16 + lrow;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int rx = wm * (TBM / 2) + i * 16 + lrow;
                 xf[i] = *reinterpret_cast<const bf16x8*>(sx + rx * 128 + ((c ^ ((rx >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -113,14 +119,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + lrow;
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = m0 + wm * (TBM / 2) + mi * 16 + lrow;
         if (m >= a.M) continue;
         const float* grow = nullptr;
         if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + lchk * 4;
+        for (int ni = 0; ni < NT; ++ni) {
+            const int n = n0 + wn * (TBN / 2) + ni * 16 + lchk * 4;
             if (n >= a.N) continue;
             f32x4 v = acc[ni][mi];
             const bool full = (n + 3 < a.N);
@@ -544,15 +550,24 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }
     }
-    const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-    dim3 grid(tiles), block(256);
+    // v1 tile shape: the largest of 128x128 / 128x64 / 64x64 that still gives every CU a tile
+    auto ntiles = [&](int bm, int bn) { return (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
+    const int shape = (force == 128 || ntiles(128, 128) >= LDT_NUM_CUS) ? 0 : (ntiles(128, 64) >= LDT_NUM_CUS ? 1 : 2);
+    dim3 block(256);
+#define LAUNCH_V1(E)                                                                                                     \
+    do {                                                                                                                 \
+        if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128>), dim3((unsigned)ntiles(128, 128)), block, 0, stream, *a); \
+        else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 64>), dim3((unsigned)ntiles(128, 64)), block, 0, stream, *a); \
+        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 64, 64>), dim3((unsigned)ntiles(64, 64)), block, 0, stream, *a);  \
+    } while (0)
     switch (epi) {
-        case EPI_F32: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_F32>, grid, block, 0, stream, *a); break;
-        case EPI_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_BF16>, grid, block, 0, stream, *a); break;
-        case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_GELU_BF16>, grid, block, 0, stream, *a); break;
-        case EPI_RELU_BF16: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_RELU_BF16>, grid, block, 0, stream, *a); break;
-        case EPI_RESID_F32: hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI_RESID_F32>, grid, block, 0, stream, *a); break;
+        case EPI_F32: LAUNCH_V1(EPI_F32); break;
+        case EPI_BF16: LAUNCH_V1(EPI_BF16); break;
+        case EPI_GELU_BF16: LAUNCH_V1(EPI_GELU_BF16); break;
+        case EPI_RELU_BF16: LAUNCH_V1(EPI_RELU_BF16); break;
+        case EPI_RESID_F32: LAUNCH_V1(EPI_RESID_F32); break;
         default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
     }
+#undef LAUNCH_V1
     return ldt_check_launch("gemm_bf16_nt");
 }
