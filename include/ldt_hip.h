@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 1
+#define LDT_ABI_VERSION 2
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -92,12 +92,14 @@ int ldt_sinusoid(const float* t, const float* freq, float* e, int32_t n, int32_t
  * mode 0 = ancestral in the reference's op order (coef[step] = {beta, std, sqrt(1-beta), sqrt(beta)});
  * mode 1 = folded x_mean = A x + B params, x = x_mean + C z (coef[step] = {A,B,C,0}).
  * z = noise[step*noise_step_stride + i] if noise != NULL (parity mode: injected CPU draws), else Philox4x32-10
- * keyed by (seed, step, elem_offset + i) — independent of how the batch is sharded across GPUs.
+ * keyed by (seed, stream id = step*philox_mul + philox_add, elem_offset + i) — independent of how the batch is
+ * sharded across GPUs; predictor-only loops use (1, 0), predictor+corrector loops number every draw.
  * step = *step_ptr if step_ptr else step_host.  x_out may alias x; x_mean_out may be NULL. */
 int ldt_sampler_step(const float* x, const float* params, const float* noise, int64_t noise_step_stride,
                      float* x_out, float* x_mean_out, const float* coef,
                      const int32_t* step_ptr, int32_t step_host, int32_t mode,
-                     int64_t n, int64_t elem_offset, uint64_t seed, void* stream);
+                     int64_t n, int64_t elem_offset, uint64_t seed,
+                     int32_t philox_mul, int32_t philox_add, void* stream);
 int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, uint64_t seed, void* stream);
 
 /* ---- Compressor encoder front end (model/Compressor/layers.py:65-112, 288-319; Network.py:26-29,76,86-107) ----

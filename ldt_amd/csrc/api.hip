@@ -90,9 +90,9 @@ extern "C" int ldt_sinusoid(const float* t, const float* freq, float* e, int32_t
 extern "C" int ldt_sampler_step(const float* x, const float* params, const float* noise, int64_t noise_step_stride,
                                 float* x_out, float* x_mean_out, const float* coef, const int32_t* step_ptr,
                                 int32_t step_host, int32_t mode, int64_t n, int64_t elem_offset, uint64_t seed,
-                                void* stream) {
+                                int32_t philox_mul, int32_t philox_add, void* stream) {
     StepArgs a{x, params, noise, x_out, x_mean_out, coef, step_ptr, step_host, mode, n, elem_offset, noise_step_stride,
-               (uint32_t)seed, (uint32_t)(seed >> 32)};
+               (uint32_t)seed, (uint32_t)(seed >> 32), philox_mul, philox_add};
     return ldt_sampler_step_launch(&a, ST(stream));
 }
 
@@ -243,7 +243,7 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
     TRY(score_forward_impl(p, x, eps_tmp, step_counter, s, nullptr));
     const long n = (long)p->batch * p->tokens * p->z_dim;
     StepArgs st{x, eps_tmp, noise, x, x_mean, coef, step_counter, 0, mode, n, elem_offset, noise_step_stride,
-                (uint32_t)seed, (uint32_t)(seed >> 32)};
+                (uint32_t)seed, (uint32_t)(seed >> 32), 1, 0};
     TRY(ldt_sampler_step_launch(&st, s));
     return ldt_advance_step_launch(step_counter, s);
 }

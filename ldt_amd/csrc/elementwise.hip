@@ -159,7 +159,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
 //   mode 1 (folded; reversediffusion / eulermaruyama / ddim, :141-191):
 //       x_mean = A*x + Bc*params ; x = x_mean + Cc*z        coef[step] = {A, Bc, Cc, 0}
 // z comes from `noise` (parity mode: injected CPU draws) or from Philox keyed by
-// (seed, step, global element index) so that a sample's noise does not depend on how the batch is sharded.
+// (seed, stream id = step*philox_mul + philox_add, global element index) so that a sample's noise does not depend on how the batch is sharded.
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
     const int step = a.step_ptr ? *a.step_ptr : a.step_host;
     const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + 4L * step);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
             z = *reinterpret_cast<const f32x4*>(nz + 4 * i);
         } else {
             const uint64_t e = (uint64_t)(a.elem_offset / 4 + i);
-            uint32_t c[4] = {(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)step, 0x4C445421u};
+            uint32_t c[4] = {(uint32_t)e, (uint32_t)(e >> 32), (uint32_t)(step * a.philox_mul + a.philox_add), 0x4C445421u};
             philox4x32_10(c, a.seed_lo, a.seed_hi);
             float z0, z1, z2, z3;
             box_muller(c[0], c[1], z0, z1);

@@ -46,6 +46,7 @@ struct StepArgs {
     const float* coef; const int* step_ptr; int step_host; int mode;
     long n; long elem_offset; long noise_step_stride;
     uint32_t seed_lo, seed_hi;
+    int philox_mul, philox_add;          // Philox stream id of this draw = step * philox_mul + philox_add
 };
 
 struct SgemmArgs {

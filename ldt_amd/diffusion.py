@@ -110,13 +110,20 @@ class DiffusionVPSDE:
     def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,
                         probability_flow, denoise, snr, device, condition=None, label=None, print_steps=None,
                         *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None):
-        """Reverse-SDE predictor(-only) sampling, diffusion_continuous.py:133-338."""
-        if corrector is not None:
-            raise NotImplementedError("correctors (langevin / ancestral, :193-229) are scheduled next (SURVEY §8f)")
+        """Reverse-SDE predictor(-corrector) sampling, diffusion_continuous.py:133-338.
+
+        corrector: None or 'ancestral' (AncestralCorrector :212-229; alpha = 1 by the reference's quirk Q11).
+        'langevin' (:193-210) and predictor 'pndm' (:260-316) multiply a (B,1) factor into (B,tokens,z) latents and
+        raise a broadcasting error in the reference itself unless B == tokens; they are rejected here too.
+        print_steps: the trajectory dump of :239-257 (returns the list of tensors)."""
+        if corrector not in (None, "ancestral"):
+            if corrector == "langevin":
+                raise NotImplementedError("LangevinCorrector: the reference broadcasts step_size[:, None] against "
+                                          "(B,tokens,z) latents (diffusion_continuous.py:208-209) and fails unless B == tokens")
+            raise NotImplementedError("corrector not Implemented")           # diffusion_continuous.py:335
         if predictor == "pndm":
-            raise NotImplementedError("PNDM (:260-316) is scheduled next (SURVEY §8f)")
-        if print_steps is not None:
-            raise NotImplementedError("print_steps trajectory dump (:239-257) is scheduled next")
+            raise NotImplementedError("PNDM: the reference's transfer() views alphas as (B,1) against (B,tokens,z) latents "
+                                      "(diffusion_continuous.py:267-271) and fails unless B == tokens")
         ts, coef, mode = self.step_table(N, predictor, time_eps, probability_flow)
         dev = torch.device(device)
         if dev.type != "cuda":
@@ -126,15 +133,16 @@ class DiffusionVPSDE:
         x = x.to(dev, torch.float32).contiguous().clone()
         if seed is None:                                       # Philox key from the (seedable) CPU generator
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ncs = corrector_steps if corrector is not None else 0  # noise draws per step: 1 predictor + ncs corrector
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
-            assert noise.shape == (N,) + tuple(x.shape), "noise must be [N, B, tokens, z]"
+            assert noise.shape == (N * (1 + ncs),) + tuple(x.shape), "noise must be [N*(1+corrector_steps), B, tokens, z]"
         coef_d = coef.to(dev)
         elem_offset = int(sample_offset) * int(np.prod(shape))
         nstride = x.numel() if noise is not None else 0
         x_mean = torch.empty_like(x)
         model = _fused_model(score_fn) if (condition is None and label is None) else None
-        if model is not None and record is None:
+        if model is not None and record is None and corrector is None and print_steps is None:
             _, mod = model.time_table(ts.to(dev))                                   # AdaLN rows for every step
             plan = model.plan(x.shape[0], x.shape[1], mod, model.n_mod, 0)          # shared by the batch
             eps_tmp = torch.empty_like(x)
@@ -145,16 +153,35 @@ class DiffusionVPSDE:
                                         coef_d.data_ptr(), mode, ops._p(noise), nstride, elem_offset, seed,
                                         counter.data_ptr(), N, int(bool(use_graph)), ops.stream_ptr()),
                   "ldt_sample_loop")
-        else:
-            ts_d = ts.to(dev)
-            for i in range(N):
-                vec_t = torch.ones((num_samples,), device=dev) * ts_d[i]             # :243-244
+            return x_mean if denoise else x
+        # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
+        ts_d = ts.to(dev)
+        if corrector is not None:                              # folded AncestralCorrector: x_mean = x - 2 snr^2 std params,
+            std = self.std(ts).double()                        # x = x_mean + 2 snr std z   (score = -params / std)
+            ccoef = torch.stack([torch.ones_like(std), -2.0 * snr * snr * std, 2.0 * snr * std, torch.zeros_like(std)], 1)
+            ccoef_d = ccoef.float().contiguous().to(dev)
+        out_list, every = None, None
+        if print_steps is not None:
+            out_list, every = [x.clone()], (N - 1) // (print_steps - 2)
+        for i in range(N):
+            vec_t = torch.ones((num_samples,), device=dev) * ts_d[i]                 # :243-244
+            _, params = score_fn(vec_t, x, label=label, condition=condition)
+            k = i * (1 + ncs)                                  # index of this step's first draw (noise row / Philox stream id)
+            x_new = ops.sampler_step(x, params.contiguous(), coef_d, i, mode, noise=None if noise is None else noise[k],
+                                     x_mean_out=x_mean, elem_offset=elem_offset, seed=seed, philox_mul=1 + ncs)
+            if record is not None:
+                record.append((x, params, x_mean.clone(), x_new))
+            x = x_new
+            for j in range(ncs):                                                     # AncestralCorrector :212-229
                 _, params = score_fn(vec_t, x, label=label, condition=condition)
-                x_new = ops.sampler_step(x, params.contiguous(), coef_d, i, mode, noise=noise, noise_step_stride=nstride,
-                                         x_mean_out=x_mean, elem_offset=elem_offset, seed=seed)
-                if record is not None:
-                    record.append((x, params, x_mean.clone(), x_new))
-                x = x_new
+                x = ops.sampler_step(x, params.contiguous(), ccoef_d, i, 1, noise=None if noise is None else noise[k + 1 + j],
+                                     x_mean_out=x_mean, elem_offset=elem_offset, seed=seed, philox_mul=1 + ncs,
+                                     philox_add=1 + j)
+            if out_list is not None and (i + 1) % every == 0:
+                out_list.append(x_mean.clone())
+        if out_list is not None:
+            out_list.append((x_mean if denoise else x).clone())
+            return out_list
         return x_mean if denoise else x
 
 

@@ -124,13 +124,14 @@ def sinusoid(t, freq):
 
 
 def sampler_step(x, params, coef, step, mode=0, noise=None, noise_step_stride=0, x_out=None, x_mean_out=None,
-                 step_ptr=None, elem_offset=0, seed=0):
+                 step_ptr=None, elem_offset=0, seed=0, philox_mul=1, philox_add=0):
     _need(x, torch.float32, "x"); _need(params, torch.float32, "params"); _need(coef, torch.float32, "coef")
     _need(noise, torch.float32, "noise")
     if x_out is None:
         x_out = torch.empty_like(x)
     check(lib().ldt_sampler_step(_p(x), _p(params), _p(noise), noise_step_stride, _p(x_out), _p(x_mean_out), _p(coef),
-                                 _p(step_ptr), int(step), mode, x.numel(), elem_offset, seed, stream_ptr()),
+                                 _p(step_ptr), int(step), mode, x.numel(), elem_offset, seed, philox_mul, philox_add,
+                                 stream_ptr()),
           "ldt_sampler_step")
     return x_out
 

@@ -210,6 +210,21 @@ def main():
         finally:
             torch.randn, torch.randn_like = o_randn, o_like
     save("other_predictors", **finals)
+    # predictor + AncestralCorrector (corrector_steps=2) and the print_steps trajectory dump, on recorded draws (a6')
+    extras = {}
+    for tag, kw in (("corr", dict(corrector="ancestral", corrector_steps=2, print_steps=None)),
+                    ("print", dict(corrector=None, corrector_steps=1, print_steps=5))):
+        torch.manual_seed(4321)
+        with Recorder() as rec2:
+            out = tr.SDE.sample_discrete(
+                score_fn=tr.score_fn, N=N, predictor="ancestral", shape=(cfg.score.z_scale, cfg.score.z_dim),
+                time_eps=cfg.sde.sample_time_eps, label=None, denoise=True, device="cpu", num_samples=B,
+                probability_flow=False, snr=cfg.sde.snr, condition=None, **kw)
+        draws = [d for _, d in rec2.draws]
+        extras[tag + "_x0"] = draws[0]
+        extras[tag + "_noise"] = torch.stack(draws[1:], 0)
+        extras[tag + "_out"] = torch.stack(out, 0) if isinstance(out, list) else out
+    save("sampler_extras", snr=cfg.sde.snr, **extras)
 
     # ---- a14-a19: Compressor decode + encode ---------------------------------------------
     geps = torch.randn(2, cfg.compressor.z_scales, cfg.compressor.n_layers * cfg.compressor.z_dim)

@@ -196,21 +196,30 @@ def score_fn_from_model(sde, model_fn):
 
 
 def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_eps=1e-6,
-                    denoise=True, probability_flow=False, record=None, max_steps=None):
-    """diffusion/diffusion_continuous.py:133-258,318-338 (pc_sampling, corrector=None).
+                    denoise=True, probability_flow=False, record=None, max_steps=None,
+                    corrector=None, corrector_steps=1, snr=0.01, print_steps=None):
+    """diffusion/diffusion_continuous.py:133-258,318-338 (pc_sampling).
 
-    x0 [B,T,z] is the initial N(0,1) draw (:237), noises[i] the step-i draw of
-    randn_like(x) (:160 etc.; the last one is drawn but unused when denoise, quirk Q8).
-    record: optional list that receives (x_in, params, x_mean, x_out) per step.
-    max_steps: stop after that many steps (bench.py's bounded CPU-baseline sample)."""
+    x0 [B,T,z] is the initial N(0,1) draw (:237); `noises` are the randn_like draws in consumption order: one per
+    predictor call (:160 etc.; the last one is drawn but unused when denoise, quirk Q8) followed by
+    `corrector_steps` per corrector call.  corrector: None or 'ancestral' (AncestralCorrector :212-229, alpha = 1
+    by quirk Q11).  LangevinCorrector (:193-210) and PNDM (:260-316) broadcast a (B,1) factor against (B,T,z)
+    latents and raise in the reference unless B == T, so they are not restated.
+    record: optional list that receives (x_in, params, x_mean, x_out) per predictor step.
+    max_steps: stop after that many steps (bench.py's bounded CPU-baseline sample).
+    print_steps: trajectory dump of :239-257 (returns the list)."""
     T = 1.0
     B = x0.shape[0]
     x = x0
     timesteps = torch.linspace(T, time_eps, N)                      # :238
     x_mean = x
+    it = iter(noises)
+    if print_steps is not None:
+        out_list = [x]
+        every = (N - 1) // (print_steps - 2)
     for i in range(N if max_steps is None else min(N, max_steps)):
         t = torch.ones((B,)) * timesteps[i]                         # :243-244
-        z = noises[i]
+        z = next(it)
         if predictor == "ancestral":                                # :152-162
             idx = (t * (N - 1) / T).long()
             beta = sde.betas[idx]
@@ -248,6 +257,21 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
         if record is not None:
             record.append((x, params, x_mean, x_new))
         x = x_new
+        if corrector == "ancestral":                                # :212-229
+            std = sde.std(t)
+            for _ in range(corrector_steps):
+                grad, params = score_fn(t, x)
+                zc = next(it)
+                step_size = (snr * std) ** 2 * 2 * torch.ones_like(t)
+                x_mean = x + step_size[:, None, None] * grad
+                x = x_mean + zc * torch.sqrt(step_size * 2)[:, None, None]
+        elif corrector is not None:
+            raise NotImplementedError("corrector not Implemented")  # :335
+        if print_steps is not None and (i + 1) % every == 0:
+            out_list.append(x_mean)
+    if print_steps is not None:
+        out_list.append(x_mean if denoise else x)
+        return out_list
     return x_mean if denoise else x
 
 

@@ -130,6 +130,28 @@ def test_other_predictors_golden(env, pred):
     assert rel_mse(out.cpu(), a[pred]) < TOL_LATENT
 
 
+def test_ancestral_corrector_and_print_steps_golden(env):
+    """predictor + AncestralCorrector (2 corrector steps) and the print_steps trajectory dump vs the reference."""
+    a, _ = load_golden("sampler_extras")
+    tr, cfg = env["tr"], env["cfg"]
+    kw = dict(score_fn=tr.score_fn, num_samples=2, N=cfg.sde.sample_N, predictor="ancestral", shape=(cfg.score.z_scale, cfg.score.z_dim),
+              time_eps=cfg.sde.sample_time_eps, probability_flow=False, denoise=True, snr=float(a["snr"]), device="cuda:0")
+    out = tr.SDE.sample_discrete(corrector="ancestral", corrector_steps=2, x0=a["corr_x0"], noise=a["corr_noise"], **kw)
+    assert rel_mse(out.cpu(), a["corr_out"]) < TOL_LATENT
+    traj = tr.SDE.sample_discrete(corrector=None, corrector_steps=1, print_steps=5, x0=a["print_x0"], noise=a["print_noise"], **kw)
+    assert isinstance(traj, list) and len(traj) == a["print_out"].shape[0]
+    assert rel_mse(torch.stack(traj).cpu(), a["print_out"]) < TOL_LATENT
+    # device-noise mode runs and is reproducible
+    o1 = tr.SDE.sample_discrete(corrector="ancestral", corrector_steps=1, x0=a["corr_x0"], seed=5, **kw)
+    o2 = tr.SDE.sample_discrete(corrector="ancestral", corrector_steps=1, x0=a["corr_x0"], seed=5, **kw)
+    assert torch.equal(o1, o2) and torch.isfinite(o1).all()
+    for bad in (dict(corrector="langevin", corrector_steps=1), dict(corrector="bogus", corrector_steps=1)):
+        with pytest.raises(NotImplementedError):
+            tr.SDE.sample_discrete(x0=a["corr_x0"], **bad, **kw)
+    with pytest.raises(NotImplementedError):
+        tr.SDE.sample_discrete(**{**kw, "predictor": "pndm"}, corrector=None, corrector_steps=1, x0=a["corr_x0"])
+
+
 def test_decoder_golden(env):
     a, _ = load_golden("decoder_tiny")
     pts = env["comp"].sample((2, 64), given_eps=a["given_eps"].cuda())

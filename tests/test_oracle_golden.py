@@ -131,6 +131,21 @@ def test_other_predictors(tiny_cfg):
         assert rel_mse(out, a[pred]) < 1e-8, pred
 
 
+def test_corrector_and_print_steps(tiny_cfg):
+    a, _ = load_golden("sampler_extras")
+    score_sd = load_golden("score_tiny")[1]["w"]
+    sde = O.VPSDE(tiny_cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, tt: O.score_forward(score_sd, tiny_cfg.score, x, tt))
+    N = tiny_cfg.sde.sample_N
+    assert a["corr_noise"].shape[0] == 3 * N                      # 1 predictor + 2 corrector draws per step
+    out = O.sample_discrete(sde, fn, a["corr_x0"], list(a["corr_noise"]), N, corrector="ancestral", corrector_steps=2,
+                            snr=float(a["snr"]))
+    assert rel_mse(out, a["corr_out"]) < 1e-8
+    traj = O.sample_discrete(sde, fn, a["print_x0"], list(a["print_noise"]), N, print_steps=5)
+    assert len(traj) == a["print_out"].shape[0]
+    assert rel_mse(torch.stack(traj), a["print_out"]) < 1e-8
+
+
 def test_decoder(tiny_cfg):
     a, _ = load_golden("decoder_tiny")
     sd = load_golden("trainer_sample_tiny")[1]["c"]
