@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 2
+#define LDT_ABI_VERSION 3
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -140,6 +140,13 @@ typedef struct ldt_score_plan {
     const uint16_t* w_up[LDT_MAX_BLOCKS];  const float* b_up[LDT_MAX_BLOCKS];  /* mlp.fc.0.0 [4h][h]   layers.py:121 */
     const uint16_t* w_dn[LDT_MAX_BLOCKS];  const float* b_dn[LDT_MAX_BLOCKS];  /* mlp.out [h][4h]      layers.py:124 */
     const uint16_t* w_out; const float* b_out;                      /* ln_out.ln [z_dim][hidden]     layers.py:239 */
+    /* Optional cross-attention (ViPC: even blocks attend to the point-cloud condition, score.py:148-149 with
+       layers.py:183-189 y != None): when kv_cond[l] != NULL block l takes K|V from kv_cond[l]
+       [batch*cond_tokens][2*hidden] bf16 — fc_kv applied to the RAW condition tokens, step-invariant, so the caller
+       projects it once per sample() call — and projects only the query with w_q[l]/b_q[l] ([hidden][hidden]). */
+    const uint16_t* w_q[LDT_MAX_BLOCKS];   const float* b_q[LDT_MAX_BLOCKS];
+    const uint16_t* kv_cond[LDT_MAX_BLOCKS];
+    int32_t cond_tokens; int32_t _pad0;
     /* AdaLN modulation: mod[step][sample][blocks*6*hidden + 2*hidden] fp32.  Block l at l*6*hidden:
        shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp (layers.py:214); FinalLayer shift|scale (:244) last. */
     const float* mod; int64_t mod_step_stride; int64_t mod_sample_stride;

@@ -151,8 +151,10 @@ static int check_plan(const ldt_score_plan* p) {
     LDT_REQUIRE(p->z_dim % 4 == 0, LDT_ESHAPE, "score: z_dim %% 4");
     LDT_REQUIRE(p->tokens > 0 && p->batch > 0, LDT_ESHAPE, "score: empty batch");
     LDT_REQUIRE(p->w_in && p->w_out && p->mod && p->xin && p->X && p->Hb && p->QKV && p->Ob && p->U, LDT_EARG, "score: null buffer in plan");
-    for (int l = 0; l < p->blocks; ++l)
+    for (int l = 0; l < p->blocks; ++l) {
         LDT_REQUIRE(p->w_qkv[l] && p->w_o[l] && p->w_up[l] && p->w_dn[l], LDT_EARG, "score: block %d weights missing", l);
+        LDT_REQUIRE(!p->kv_cond[l] || (p->w_q[l] && p->cond_tokens > 0), LDT_EARG, "score: block %d cross-attention needs w_q and cond_tokens", l);
+    }
     return LDT_OK;
 }
 
@@ -189,11 +191,20 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         const float* m = p->mod + (long)l * 6 * D;              // shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
         LnArgs n1{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n1, s));
-        GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
-        LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
-        AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
-                    BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
-        LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        if (p->kv_cond[l]) {                                    // cross-attention: q from the modulated x, K|V from the condition
+            const int S = p->cond_tokens;
+            GemmArgs gq{BF(p->Hb), D, BF(p->w_q[l]), D, p->b_q[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, D};
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->kv_cond[l]), 2L * D, (long)S * 2 * D, BF(p->kv_cond[l]) + D, 2L * D,
+                        BFM(p->Ob), p->batch, p->heads, T, S, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
+            LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        } else {                                                // self-attention: fused q|k|v projection of the modulated x
+            GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
+                        BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
+            LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        }
         GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
         LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
         LnArgs n2{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m + 3 * D, m + 4 * D, sstr, T, step_ptr, tstr, M, D};

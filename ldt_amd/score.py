@@ -41,7 +41,12 @@ class Score(nn.Module):
         self.unet = cfg.unet
         self.AdaLN = cfg.AdaLN
         if self.condition:
-            raise NotImplementedError("ViPC ConditionNet (score.py:13-44) is scheduled next (SURVEY §8f)")
+            # ConditionNet (score.py:13-44) wraps a torchvision resnet18 trunk + a LocalGrouper; it runs ONCE per
+            # sample() call, outside the loop.  Its parameters are not built here: pass the already-embedded
+            # condition tuple (pts_condition (B,hidden,S) or None, img_condition (B,t_dim) or 0.) to forward().
+            raise NotImplementedError("cfg.score.condition=True builds ConditionNet (torchvision resnet18), which is not part "
+                                      "of this path; construct Score with condition=False and pass the embedded "
+                                      "condition tuple to forward(..., condition=(pts_cond, img_cond))")
         if self.unet:
             raise NotImplementedError("unet: True Score variant (score.py:67-83) is not on the shipped path")
         if not self.AdaLN or getattr(cfg, "dropout", 0.):
@@ -62,6 +67,7 @@ class Score(nn.Module):
         self._pack_key = None
         self._ws = {}
         self._freq = None
+        self._cond_cache = {}
 
     # ------------------------------------------------------------------ packed weights
     @property
@@ -96,7 +102,36 @@ class Score(nn.Module):
             P["w_out"] = ops.cast_pad_bf16(w, w.shape[1])
             P["b_out"] = self.ln_out.ln.bias.detach().float().contiguous()
         self._pack, self._pack_key = P, key
+        self._cond_cache = {}
         return P
+
+    def _cross_panels(self, l):
+        """bf16 fc_q and fc_kv panels of block l as separate operands (cross-attention: layers.py:186-189)."""
+        P = self.packed()
+        if ("w_q", l) not in P:
+            blk = self.Transformer[l]
+            with torch.no_grad():
+                wq = conv_w(blk.fc_q).float().contiguous(); wkv = conv_w(blk.fc_kv).float().contiguous()
+                P[("w_q", l)] = ops.cast_pad_bf16(wq, wq.shape[1]); P[("b_q", l)] = blk.fc_q.bias.detach().float().contiguous()
+                P[("w_kv", l)] = ops.cast_pad_bf16(wkv, wkv.shape[1]); P[("b_kv", l)] = blk.fc_kv.bias.detach().float().contiguous()
+        return P[("w_q", l)], P[("b_q", l)], P[("w_kv", l)], P[("b_kv", l)]
+
+    def project_condition(self, pts_cond):
+        """pts_cond (B, hidden, S) channels-first (what ConditionNet returns, score.py:41-44) -> per even block the
+        K|V rows [B*S, 2*hidden] bf16.  Step-invariant: computed once and cached per condition tensor."""
+        key = (pts_cond.data_ptr(), pts_cond._version, tuple(pts_cond.shape))
+        self.packed()
+        if key not in self._cond_cache:
+            from ._lib import EPI_BF16
+            B, C, S = pts_cond.shape
+            y = pts_cond.to(self._device(), torch.float32).transpose(1, 2).contiguous().view(B * S, C)   # token-major raw y
+            yb = ops.cast_pad_bf16(y, C)
+            kv = {}
+            for l in range(0, self.num_blocks, 2):                                  # score.py:149: idx % 2 == 0
+                _, _, wkv, bkv = self._cross_panels(l)
+                kv[l] = ops.gemm_bf16(yb, wkv, bkv, EPI_BF16)
+            self._cond_cache = {key: (kv, S)}
+        return self._cond_cache[key]
 
     def _workspace(self, B, T):
         k = (B, T, self._device())
@@ -111,8 +146,8 @@ class Score(nn.Module):
             }}
         return self._ws[k]
 
-    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride):
-        """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`."""
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0):
+        """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows}."""
         P, W = self.packed(), self._workspace(B, T)
         p = ScorePlan()
         p.hidden, p.heads, p.blocks = self.hidden_size, self.num_heads, self.num_blocks
@@ -127,7 +162,12 @@ class Score(nn.Module):
         p.mod, p.mod_step_stride, p.mod_sample_stride = mod.data_ptr(), mod_step_stride, mod_sample_stride
         for nm in ("xin", "X", "Hb", "QKV", "Ob", "U"):
             setattr(p, nm, W[nm].data_ptr())
-        p._keep = (P, W, mod)            # keep the buffers alive as long as the plan
+        if kv_cond:
+            p.cond_tokens = cond_tokens
+            for l, kv in kv_cond.items():
+                wq, bq, _, _ = self._cross_panels(l)
+                p.w_q[l], p.b_q[l], p.kv_cond[l] = wq.data_ptr(), bq.data_ptr(), kv.data_ptr()
+        p._keep = (P, W, mod, kv_cond)   # keep the buffers alive as long as the plan
         return p
 
     # ------------------------------------------------------------------ AdaLN tables
@@ -159,18 +199,41 @@ class Score(nn.Module):
         return c, mod
 
     # ------------------------------------------------------------------ reference API
+    def label_embedding(self, label):
+        """LabelEmbedding (model/layers.py:44-52): mlp(Embedding[label]) -> (B, t_dim)."""
+        if not hasattr(self, "LabelEmbedding"):
+            raise ValueError("label given but cfg.score.num_categorys <= 1 (no LabelEmbedding, score.py:103-106)")
+        le = self.LabelEmbedding
+        e = le.label_emb.weight.detach()[label.to(self._device()).long()].float().contiguous()      # row gather
+        h = ops.sgemm(e, le.mlp[0].weight, le.mlp[0].bias, act_out=ACT_SILU)
+        return ops.sgemm(h, le.mlp[2].weight, le.mlp[2].bias)
+
     @torch.no_grad()
     def forward(self, x, t, label=None, condition=None):
-        """x (bs, tokens, z_dim), t (bs,) -> predicted noise (bs, tokens, z_dim)   [score.py:117-151]"""
-        if label is not None or condition is not None:
-            raise NotImplementedError("label / ViPC conditioning is scheduled next (SURVEY §8f)")
+        """x (bs, tokens, z_dim), t (bs,) -> predicted noise (bs, tokens, z_dim)   [score.py:117-151]
+
+        label: (bs,) class ids (LabelEmbedding, num_categorys > 1).  condition: the EMBEDDED pair the reference's
+        ConditionNet returns — (pts_condition (bs, hidden, S) or None, img_condition (bs, t_dim) or 0.) — cross-
+        attended on even blocks / added to the time embedding (score.py:135,148-149; a label wins over the image
+        condition by the reference's operator precedence).  A raw dict would need ConditionNet (see __init__)."""
+        if isinstance(condition, dict):
+            raise NotImplementedError("raw ViPC condition dicts need ConditionNet (resnet18 trunk); pass its output tuple")
         if not x.is_cuda:
             raise RuntimeError("Score.forward: x is on %s; the HIP path has no CPU fallback" % x.device)
         B, T, z = x.shape
         assert z == self.z_dim
         x = x.contiguous().float()
-        _, mod = self.time_table(t.to(x).float())
-        plan = self.plan(B, T, mod, 0, self.n_mod)            # per-sample AdaLN rows
+        pts_cond, img_cond = (None, 0.) if condition is None else condition
+        extra = None
+        if label is not None:
+            extra = self.label_embedding(label)
+        elif torch.is_tensor(img_cond):
+            extra = img_cond.to(x).float()
+        _, mod = self.time_table(t.to(x).float(), extra_c=extra)
+        kv, S = (None, 0)
+        if torch.is_tensor(pts_cond):
+            kv, S = self.project_condition(pts_cond)
+        plan = self.plan(B, T, mod, 0, self.n_mod, kv_cond=kv, cond_tokens=S)      # per-sample AdaLN rows
         out = torch.empty_like(x)
         check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), None, ops.stream_ptr()),
               "ldt_score_forward")

@@ -43,6 +43,44 @@ def test_score_forward_golden(env):
     assert rel_mse(out.cpu(), a["out"]) < TOL_PARAMS
 
 
+def test_score_forward_conditioned_golden(env):
+    """ViPC-style conditioning (score.py:135,148-149): img condition added to the time embedding, point-cloud
+    condition cross-attended on even blocks (K/V from the RAW condition, projected once and cached)."""
+    a, _ = load_golden("score_tiny")
+    pts = a["pts_cond"].transpose(1, 2).contiguous().cuda()          # back to the reference's channels-first (B,hidden,S)
+    out = env["score"](a["x"].cuda(), a["t"].cuda(), condition=(pts, a["img_cond"].cuda()))
+    assert rel_mse(out.cpu(), a["out_cond"]) < TOL_PARAMS
+    assert rel_mse(out.cpu(), a["out"]) > 1e-3                       # and it is not the unconditional answer
+    again = env["score"](a["x"].cuda(), a["t"].cuda(), condition=(pts, a["img_cond"].cuda()))
+    assert torch.equal(out, again)                                    # cached K/V projection path
+    only_img = env["score"](a["x"].cuda(), a["t"].cuda(), condition=(None, a["img_cond"].cuda()))
+    ref = env["O"].score_forward(env["ssd"], env["cfg"].score, a["x"], a["t"], condition=(None, a["img_cond"]))
+    assert rel_mse(only_img.cpu(), ref) < TOL_PARAMS
+    with pytest.raises(NotImplementedError):
+        env["score"](a["x"].cuda(), a["t"].cuda(), condition={"pts": pts})
+
+
+def test_label_conditioning_vs_oracle(tiny_cfg):
+    """Class-conditional Score (num_categorys > 1): c = t_emb + LabelEmbedding(label) (score.py:125-135)."""
+    import copy
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.num_categorys = 5
+    torch.manual_seed(9)
+    score = ldt_amd.Score(cfg.score)
+    sd = {k: v.detach().clone() for k, v in score.state_dict().items()}
+    score = score.cuda()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, cfg.score.z_scale, cfg.score.z_dim, generator=g); t = torch.tensor([0.8, 0.2, 0.01])
+    label = torch.tensor([4, 0, 2])
+    out = score(x.cuda(), t.cuda(), label=label.cuda())
+    emb = torch.nn.functional.embedding(label, sd["LabelEmbedding.label_emb.weight"])
+    l_emb = O.linear(sd, "LabelEmbedding.mlp.2", torch.nn.functional.silu(O.linear(sd, "LabelEmbedding.mlp.0", emb)))
+    ref = O.score_forward(sd, cfg.score, x, t, label_emb=l_emb)
+    assert rel_mse(out.cpu(), ref) < TOL_PARAMS
+
+
 def test_time_table_matches_oracle(env):
     """c and every AdaLN row in fp32: the batch-shared table == per-sample evaluation."""
     O, score, cfg = env["O"], env["score"], env["cfg"]

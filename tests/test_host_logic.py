@@ -142,6 +142,10 @@ def test_unsupported_options_raise(tiny_cfg):
     import copy
     import ldt_amd
     c = copy.deepcopy(tiny_cfg)
+    c.score.condition = True                      # would build ConditionNet (torchvision resnet18)
+    with pytest.raises(NotImplementedError):
+        ldt_amd.Score(c.score)
+    c = copy.deepcopy(tiny_cfg)
     c.score.unet = True
     with pytest.raises(NotImplementedError):
         ldt_amd.Score(c.score)
