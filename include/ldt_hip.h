@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 3
+#define LDT_ABI_VERSION 4
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -178,14 +178,28 @@ enum ldt_prof_class {
 int ldt_score_forward_profile(const ldt_score_plan* plan, const float* x, float* eps_out, const int32_t* step_ptr,
                               float* ms_by_class, int32_t* launches_by_class, void* stream);
 
+/* Per-sample conditioning inside the loop (label / ViPC image embedding, score.py:125-135): the AdaLN rows then
+ * differ per sample and per step, c[b] = TimeEmbedding(t_i) + extra[b], mod[b] = W_ada · SiLU(c[b]) + b_ada, and are
+ * recomputed every step by two extra launches (row add, fp32 SGEMM over the stacked adaLN weights). */
+typedef struct ldt_cond_args {
+    const float* temb;    /* [n_steps][t_dim]  TimeEmbedding(t_i) for every step (host builds it once per call) */
+    const float* extra;   /* [batch][t_dim]    label / image-condition embedding, or NULL */
+    const float* w_ada;   /* [n_mod][t_dim]    every block's adaLN.1 weight stacked in plan order (+ FinalLayer's) */
+    const float* b_ada;   /* [n_mod] */
+    float* c_buf;         /* [batch][t_dim]    scratch */
+    float* mod_buf;       /* [batch][n_mod]    scratch; plan->mod must point here with mod_sample_stride = n_mod */
+    int32_t t_dim, n_mod;
+} ldt_cond_args;
+
 /* The whole reverse-SDE loop (pc_sampling, diffusion_continuous.py:231-258 with corrector None): n_steps x
- * [Score forward -> predictor update -> ++step].  x is updated in place, x_mean receives the last x_mean
- * (denoise=True returns it, quirk Q8).  step_counter: device int32 scratch.  use_graph != 0 captures one
- * step into a hipGraph and replays it. */
+ * [(AdaLN rows if cond) -> Score forward -> predictor update -> ++step].  x is updated in place, x_mean receives the
+ * last x_mean (denoise=True returns it, quirk Q8).  step_counter: device int32 scratch.  cond: NULL for the
+ * unconditional sampler (plan->mod = table of all steps).  use_graph != 0 captures one step into a hipGraph and
+ * replays it. */
 int ldt_sample_loop(const ldt_score_plan* plan, float* x, float* x_mean, float* eps_tmp,
                     const float* coef, int32_t mode, const float* noise, int64_t noise_step_stride,
                     int64_t elem_offset, uint64_t seed, int32_t* step_counter, int32_t n_steps,
-                    int32_t use_graph, void* stream);
+                    const ldt_cond_args* cond, int32_t use_graph, void* stream);
 
 #ifdef __cplusplus
 }

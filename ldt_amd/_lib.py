@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -34,6 +34,11 @@ class ScorePlan(C.Structure):
     )
 
 
+class CondArgs(C.Structure):
+    """Mirror of `ldt_cond_args` (include/ldt_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("temb", "extra", "w_ada", "b_ada", "c_buf", "mod_buf")] + [("t_dim", _i32), ("n_mod", _i32)]
+
+
 # name -> argtypes; every symbol include/ldt_hip.h declares (tests/test_abi.py checks the two lists agree)
 SIGNATURES = {
     "ldt_abi_version": [],
@@ -57,7 +62,7 @@ SIGNATURES = {
     "ldt_chamfer": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ldt_score_forward": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp],
     "ldt_score_forward_profile": [C.POINTER(ScorePlan), _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp],
-    "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, _i32, _vp],
+    "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, C.POINTER(CondArgs), _i32, _vp],
 }
 
 _lib = None

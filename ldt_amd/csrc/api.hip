@@ -250,8 +250,14 @@ extern "C" int ldt_score_forward_profile(const ldt_score_plan* p, const float* x
 // ------------------------------------------------------------------------------ reverse-SDE loop
 static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef, int mode,
                         const float* noise, long noise_step_stride, long elem_offset, uint64_t seed, int* step_counter,
-                        hipStream_t s) {
-    TRY(score_forward_impl(p, x, eps_tmp, step_counter, s, nullptr));
+                        const ldt_cond_args* cond, hipStream_t s) {
+    if (cond) {                                                 // per-sample AdaLN rows of this step
+        TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, step_counter, p->batch, cond->t_dim, s));
+        SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_SILU,
+                    LDT_ACT_NONE, p->batch, cond->n_mod, cond->t_dim};
+        TRY(ldt_sgemm_launch(&g, s));
+    }
+    TRY(score_forward_impl(p, x, eps_tmp, cond ? nullptr : step_counter, s, nullptr));
     const long n = (long)p->batch * p->tokens * p->z_dim;
     StepArgs st{x, eps_tmp, noise, x, x_mean, coef, step_counter, 0, mode, n, elem_offset, noise_step_stride,
                 (uint32_t)seed, (uint32_t)(seed >> 32), 1, 0};
@@ -261,15 +267,19 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
 
 extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef,
                                int32_t mode, const float* noise, int64_t noise_step_stride, int64_t elem_offset,
-                               uint64_t seed, int32_t* step_counter, int32_t n_steps, int32_t use_graph, void* stream) {
+                               uint64_t seed, int32_t* step_counter, int32_t n_steps, const ldt_cond_args* cond,
+                               int32_t use_graph, void* stream) {
     TRY(check_plan(p));
     LDT_REQUIRE(x && x_mean && eps_tmp && coef && step_counter && n_steps > 0, LDT_EARG, "sample_loop: null pointer / n_steps");
+    LDT_REQUIRE(!cond || (cond->temb && cond->w_ada && cond->c_buf && cond->mod_buf && cond->mod_buf == p->mod &&
+                          p->mod_sample_stride == cond->n_mod && cond->t_dim > 0), LDT_EARG,
+                "sample_loop: inconsistent conditioning block (plan->mod must be cond->mod_buf with sample stride n_mod)");
     hipStream_t s = ST(stream);
     hipError_t e = hipMemsetAsync(step_counter, 0, sizeof(int), s);
     if (e != hipSuccess) { ldt_set_error("sample_loop: memset: %s", hipGetErrorString(e)); return (int)e; }
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i)
-            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, s));
+            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, s));
         return LDT_OK;
     }
     // One step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter.
@@ -298,7 +308,7 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     if (status == LDT_OK) {
         HIPTRY(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal), "begin capture");
         if (status == LDT_OK) {
-            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, gs);
+            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, gs);
             const hipError_t ee = hipStreamEndCapture(gs, &graph);
             if (rc != LDT_OK) status = rc;
             else if (ee != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(ee)); status = (int)ee; }

@@ -327,3 +327,19 @@ int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s) {
     hipLaunchKernelGGL(sgemm_nt_kernel, grid, block, 0, s, *a);
     return ldt_check_launch("sgemm_nt");
 }
+
+// c[b][k] = temb[step][k] + extra[b][k]   (score.py:135: c = t_emb + l_emb | img condition), step from the device counter
+__global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __restrict__ extra, float* __restrict__ c,
+                                 const int* __restrict__ step_ptr, int batch, int t_dim) {
+    const int step = step_ptr ? *step_ptr : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < batch * t_dim; i += gridDim.x * blockDim.x) {
+        const int k = i % t_dim;
+        c[i] = temb[(long)step * t_dim + k] + (extra ? extra[i] : 0.f);
+    }
+}
+int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, hipStream_t s) {
+    LDT_REQUIRE(temb && c && batch > 0 && t_dim > 0, LDT_EARG, "cond_rows: bad arguments");
+    int blocks = (batch * t_dim + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(cond_rows_kernel, dim3(blocks), dim3(256), 0, s, temb, extra, c, step_ptr, batch, t_dim);
+    return ldt_check_launch("cond_rows");
+}

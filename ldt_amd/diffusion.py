@@ -141,18 +141,33 @@ class DiffusionVPSDE:
         elem_offset = int(sample_offset) * int(np.prod(shape))
         nstride = x.numel() if noise is not None else 0
         x_mean = torch.empty_like(x)
-        model = _fused_model(score_fn) if (condition is None and label is None) else None
+        model = _fused_model(score_fn)
         if model is not None and record is None and corrector is None and print_steps is None:
-            _, mod = model.time_table(ts.to(dev))                                   # AdaLN rows for every step
-            plan = model.plan(x.shape[0], x.shape[1], mod, model.n_mod, 0)          # shared by the batch
+            from ._lib import CondArgs
+            B, T = x.shape[0], x.shape[1]
             eps_tmp = torch.empty_like(x)
             counter = torch.zeros(1, dtype=torch.int32, device=dev)
             if use_graph is None:
-                use_graph = x.shape[0] * x.shape[1] <= 4096                          # launch-bound regime only
+                use_graph = B * T <= 4096                                             # launch-bound regime only
+            cond_ref, keep = None, None
+            if condition is None and label is None:
+                _, mod = model.time_table(ts.to(dev))                                 # AdaLN rows for every step ...
+                plan = model.plan(B, T, mod, model.n_mod, 0)                          # ... shared by the batch
+            else:                                                                     # per-sample rows, rebuilt every step
+                extra, kv, S = model.condition_embedding(label, condition)
+                temb = model.time_embedding(ts.to(dev))
+                w_ada, b_ada = model.stacked_adaln()
+                c_buf = torch.empty((B, model.t_dim), dtype=torch.float32, device=dev)
+                mod = torch.empty((B, model.n_mod), dtype=torch.float32, device=dev)
+                plan = model.plan(B, T, mod, 0, model.n_mod, kv_cond=kv, cond_tokens=S)
+                cond = CondArgs(temb.data_ptr(), ops._p(extra), w_ada.data_ptr(), b_ada.data_ptr(), c_buf.data_ptr(),
+                                mod.data_ptr(), model.t_dim, model.n_mod)
+                cond_ref, keep = ctypes.byref(cond), (extra, temb, w_ada, b_ada, c_buf, mod, cond)
             check(lib().ldt_sample_loop(ctypes.byref(plan), x.data_ptr(), x_mean.data_ptr(), eps_tmp.data_ptr(),
                                         coef_d.data_ptr(), mode, ops._p(noise), nstride, elem_offset, seed,
-                                        counter.data_ptr(), N, int(bool(use_graph)), ops.stream_ptr()),
+                                        counter.data_ptr(), N, cond_ref, int(bool(use_graph)), ops.stream_ptr()),
                   "ldt_sample_loop")
+            torch.cuda.current_stream().synchronize() if keep is not None else None   # scratch must outlive the loop
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)

@@ -105,6 +105,39 @@ class Score(nn.Module):
         self._cond_cache = {}
         return P
 
+    def stacked_adaln(self):
+        """Every adaLN Linear stacked in mod-row order ([n_mod][t_dim] fp32 + [n_mod]) for the one-launch per-step
+        AdaLN of the conditional sampler (ldt_cond_args.w_ada); built on first use, dropped on repack."""
+        P = self.packed()
+        if "w_ada" not in P:
+            with torch.no_grad():
+                lins = [blk.adaLN[1] for blk in self.Transformer] + [self.ln_out.adaLN[1]]
+                P["w_ada"] = torch.cat([l.weight.detach().float() for l in lins], 0).contiguous()
+                P["b_ada"] = torch.cat([l.bias.detach().float() for l in lins], 0).contiguous()
+        return P["w_ada"], P["b_ada"]
+
+    def time_embedding(self, t):
+        """TimeEmbedding(t) only: t [n] -> c [n, t_dim] fp32 (model/layers.py:38-41)."""
+        te = self.TimeEmbedding.mlp
+        e = ops.sinusoid(t.contiguous(), self._frequencies())
+        h = ops.sgemm(e, te[0].weight, te[0].bias, act_out=ACT_SILU)
+        return ops.sgemm(h, te[2].weight, te[2].bias)
+
+    def condition_embedding(self, label=None, condition=None):
+        """-> (extra [B,t_dim] or None, kv_cond {block: K|V} or None, cond_tokens) for forward()/the fused loop."""
+        if isinstance(condition, dict):
+            raise NotImplementedError("raw ViPC condition dicts need ConditionNet (resnet18 trunk); pass its output tuple")
+        pts_cond, img_cond = (None, 0.) if condition is None else condition
+        extra = None
+        if label is not None:
+            extra = self.label_embedding(label)                      # a label wins over the image condition (score.py:135)
+        elif torch.is_tensor(img_cond):
+            extra = img_cond.to(self._device(), torch.float32).contiguous()
+        kv, S = (None, 0)
+        if torch.is_tensor(pts_cond):
+            kv, S = self.project_condition(pts_cond)
+        return extra, kv, S
+
     def _cross_panels(self, l):
         """bf16 fc_q and fc_kv panels of block l as separate operands (cross-attention: layers.py:186-189)."""
         P = self.packed()
@@ -216,23 +249,13 @@ class Score(nn.Module):
         ConditionNet returns — (pts_condition (bs, hidden, S) or None, img_condition (bs, t_dim) or 0.) — cross-
         attended on even blocks / added to the time embedding (score.py:135,148-149; a label wins over the image
         condition by the reference's operator precedence).  A raw dict would need ConditionNet (see __init__)."""
-        if isinstance(condition, dict):
-            raise NotImplementedError("raw ViPC condition dicts need ConditionNet (resnet18 trunk); pass its output tuple")
         if not x.is_cuda:
             raise RuntimeError("Score.forward: x is on %s; the HIP path has no CPU fallback" % x.device)
         B, T, z = x.shape
         assert z == self.z_dim
         x = x.contiguous().float()
-        pts_cond, img_cond = (None, 0.) if condition is None else condition
-        extra = None
-        if label is not None:
-            extra = self.label_embedding(label)
-        elif torch.is_tensor(img_cond):
-            extra = img_cond.to(x).float()
+        extra, kv, S = self.condition_embedding(label, condition)
         _, mod = self.time_table(t.to(x).float(), extra_c=extra)
-        kv, S = (None, 0)
-        if torch.is_tensor(pts_cond):
-            kv, S = self.project_condition(pts_cond)
         plan = self.plan(B, T, mod, 0, self.n_mod, kv_cond=kv, cond_tokens=S)      # per-sample AdaLN rows
         out = torch.empty_like(x)
         check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), None, ops.stream_ptr()),

@@ -95,6 +95,11 @@ class Trainer:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             x0_loc = _rows(x0, lo, hi, per)
             noise_loc = None if noise is None else _rows(noise.transpose(0, 1), lo, hi, per).transpose(0, 1)
+            if ws > 1:                                   # per-sample conditioning follows its samples to their rank
+                if torch.is_tensor(label):
+                    label = _rows(label, lo, hi, per)
+                if isinstance(condition, (tuple, list)):
+                    condition = tuple(_rows(c, lo, hi, per) if torch.is_tensor(c) else c for c in condition)
             eps = self.SDE.sample_discrete(score_fn=self.score_fn, N=self.cfg.sde.sample_N,
                                            corrector=self.cfg.sde.corrector, predictor=self.cfg.sde.predictor,
                                            corrector_steps=self.cfg.sde.corrector_steps, shape=shape,

@@ -60,6 +60,28 @@ def test_score_forward_conditioned_golden(env):
         env["score"](a["x"].cuda(), a["t"].cuda(), condition={"pts": pts})
 
 
+def test_conditioned_sampling_loop_vs_oracle(env):
+    """Fused conditional loop (per-sample AdaLN rows recomputed in C++ every step + cross-attention) == the
+    Python-driven loop == the oracle with the same condition, on injected noise."""
+    O, tg, tr, cfg = env["O"], env["tg"], env["tr"], env["cfg"]
+    a, _ = load_golden("score_tiny")
+    pts_tm = a["pts_cond"][:2]; img = a["img_cond"][:2]                     # token-major [B,S,hidden] / [B,t_dim]
+    cond_dev = (pts_tm.transpose(1, 2).contiguous().cuda(), img.cuda())
+    kw = dict(score_fn=tr.score_fn, num_samples=2, N=cfg.sde.sample_N, predictor="ancestral", corrector=None, corrector_steps=1,
+              shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=False,
+              denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"], condition=cond_dev)
+    fused = tr.SDE.sample_discrete(**kw, use_graph=0)
+    graph = tr.SDE.sample_discrete(**kw, use_graph=1)
+    assert torch.equal(fused, graph)
+    generic = tr.SDE.sample_discrete(**kw, record=[])
+    assert rel_mse(generic.cpu(), fused.cpu()) < 1e-6
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(env["ssd"], cfg.score, x, t, condition=(pts_tm, img)))
+    ref = O.sample_discrete(sde, fn, tg["x0"], list(tg["noises"]), cfg.sde.sample_N)
+    assert rel_mse(fused.cpu(), ref) < TOL_LATENT
+    assert rel_mse(fused.cpu(), tg["eps"]) > 1e-3                            # differs from the unconditional trajectory
+
+
 def test_label_conditioning_vs_oracle(tiny_cfg):
     """Class-conditional Score (num_categorys > 1): c = t_emb + LabelEmbedding(label) (score.py:125-135)."""
     import copy
