@@ -180,7 +180,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", init_method="env://")       # RCCL over xGMI; MASTER_* / RANK from the launcher
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
@@ -196,7 +196,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     log("model built on %s (world %d), B=%d T=%d N=%d" % (device, world, B, args.tokens, args.sde_steps))
@@ -244,7 +244,7 @@ def main():
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
