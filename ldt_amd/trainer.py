@@ -66,7 +66,7 @@ class Trainer:
         self.sample_time_eps = cfg.sde.sample_time_eps
         self.sample_N = cfg.sde.sample_N
         self.sample_mode = cfg.sde.sample_mode
-        self.epoch, self.itr = 1, 0
+        self.epoch, self.itr, self.time = 1, 0, 0.
 
     def score_fn(self, t, x, label=None, condition=None):
         t = t.to(x)
@@ -135,16 +135,38 @@ class Trainer:
         return smp, rate
 
     # ---- checkpoints: the reference's dict layout (:228-266) ------------------------------------------
-    def resume(self, path, strict=True):
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    def resume(self, epoch=None, strict=False, load_optim=True, finetune=False, pretrain=None, **kwargs):
+        """Same arguments as the reference (:241-266): the file is `pretrain` if given, else
+        `<cfg.log.save_path>/checkpt_<epoch>.pth` with `epoch` defaulting to the last row of `training.csv`.
+        (A path string passed as `epoch` is accepted as shorthand for `pretrain=`.)  Loads both state dicts, adopts
+        the optimizer's per-parameter 'ema' tensors (unless finetune / load_optim=False) and re-runs
+        `compressor.init()`."""
+        import os
+        if finetune:
+            load_optim, strict = False, False
+        if isinstance(epoch, (str, os.PathLike)):
+            pretrain, epoch = epoch, None
+        if pretrain is None:
+            if epoch is None:
+                import csv
+                with open(os.path.join(self.cfg.log.save_path, "training.csv")) as f:
+                    epoch = int(float(list(csv.DictReader(f))[-1]["epoch"]))
+            pretrain = os.path.join(self.cfg.log.save_path, "checkpt_{:}.pth".format(epoch))
+        ckpt = torch.load(pretrain, map_location="cpu", weights_only=False)   # holds cfg as argparse.Namespace
         self.model.load_state_dict(ckpt["score_state_dict"], strict=strict)
         self.compressor.load_state_dict(ckpt["compressor_state_dict"], strict=strict)
-        if "score_optim_state_dict" in ckpt:
-            self.optimizer.load_ema(ckpt["score_optim_state_dict"])
         self.compressor.init()
-        self.epoch, self.itr = ckpt.get("epoch", 1), ckpt.get("itr", 0)
+        if load_optim:
+            self.optimizer.load_ema(ckpt["score_optim_state_dict"])
+        if finetune:
+            self.epoch, self.itr = 1, 0
+        else:
+            self.epoch, self.itr = ckpt["epoch"] + 1, ckpt["itr"]
+        self.time = ckpt["time"]
 
-    def load_pretrain(self, path):
+    def load_pretrain(self, path=None):
+        """Stage-1 compressor checkpoint (:268-273): key `state_dict`, strict."""
+        path = self.cfg.compressor.pretrain_path if path is None else path
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
         self.compressor.load_state_dict(ckpt["state_dict"], strict=True)
         self.compressor.init()

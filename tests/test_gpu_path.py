@@ -278,3 +278,25 @@ def test_no_cpu_fallback(env):
     a, _ = load_golden("score_tiny")
     with pytest.raises(RuntimeError):
         env["score"](a["x"], a["t"])
+
+
+def test_resume_reference_checkpoint_then_sample_golden():
+    """(f)3: a checkpoint written by the reference's `Trainer.save` (tests/golden/checkpoint_tiny.pth) is resumed
+    by `ldt_amd.Trainer`, `sample` swaps the optimizer's EMA weights in (repacking the bf16 panels) and reproduces
+    the latents the reference produced after its own `resume` + `sample`; with EMA off it reproduces the raw-weight run."""
+    import os
+    import ldt_amd
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "checkpoint_tiny.pth")
+    a, _ = load_golden("checkpoint_tiny_expect")
+    cfg = torch.load(path, map_location="cpu", weights_only=False)["cfg"]
+    torch.manual_seed(9)
+    tr = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor), "cuda:0")
+    tr.resume(pretrain=path, strict=True)
+    pts, eps = tr.sample(2, x0=a["x0"], noise=a["noises"])
+    assert rel_mse(eps.cpu(), a["eps"]) < TOL_LATENT
+    assert pts.shape == a["points"].shape and torch.isfinite(pts).all()
+    tr.optimizer.apply_ema = False
+    _, eps_raw = tr.sample(2, x0=a["x0"], noise=a["noises"])
+    assert rel_mse(eps_raw.cpu(), a["eps_raw_weights"]) < TOL_LATENT
+    assert rel_mse(eps_raw.cpu(), a["eps"]) > 30 * TOL_LATENT         # the swap matters (golden: 9.9e-3)

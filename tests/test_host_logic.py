@@ -172,3 +172,45 @@ def test_default_init_draws_same_weights_as_reference(tiny_cfg):
         assert list(sa) == list(sb)
         for k in sa:
             assert torch.equal(sa[k], sb[k]), k
+
+
+def test_resume_reads_reference_checkpoint_layout():
+    """(f)3: `Trainer.resume` on a file written by the reference's `Trainer.save` (oracle/gen_checkpoint_golden.py):
+    state dicts load strictly, epoch/itr follow :262-265, and the optimizer's 'ema' tensors land on the parameters
+    with the same NAMES (the file keys them by position) so that the swap installs them."""
+    import ldt_amd
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "checkpoint_tiny.pth")
+    a, sds = load_golden("checkpoint_tiny_expect")
+    cfg = torch.load(path, map_location="cpu", weights_only=False)["cfg"]     # the reference pickles its Namespace
+    torch.manual_seed(123)
+    score, comp = ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor)
+    tr = ldt_amd.Trainer(cfg, score, comp, "cpu")
+    tr.resume(pretrain=path, strict=True)
+    assert (tr.epoch, tr.itr, tr.time) == (int(a["epoch_after_resume"]), int(a["itr"]), 4.5)
+    named = dict(score.named_parameters())
+    assert len(tr.optimizer.state) == int(a["n_params"]) == len(named)
+    for name, ema in sds["ema"].items():
+        assert torch.equal(tr.optimizer.state[named[name]]["ema"], ema), name
+        assert torch.equal(named[name].detach(), sds["raw"][name]), name
+    tr.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
+    for name, ema in sds["ema"].items():
+        assert torch.equal(named[name].detach(), ema)
+    tr.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
+    for name in sds["ema"]:
+        assert torch.equal(named[name].detach(), sds["raw"][name])
+    # the reference's path convention: <save_path>/checkpt_<epoch>.pth, epoch from training.csv when omitted
+    import shutil, tempfile
+    d = tempfile.mkdtemp()
+    try:
+        shutil.copyfile(path, os.path.join(d, "checkpt_7.pth"))
+        with open(os.path.join(d, "training.csv"), "w") as f:
+            f.write("epoch,itr,loss,time\n3,10,0.5,1\n7,123,0.4,2\n")
+        cfg.log.save_path = d
+        tr2 = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor), "cpu")
+        tr2.resume()
+        assert tr2.epoch == 8
+        tr2.resume(epoch=7, finetune=True)
+        assert (tr2.epoch, tr2.itr) == (1, 0)
+    finally:
+        shutil.rmtree(d)

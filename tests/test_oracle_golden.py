@@ -190,3 +190,26 @@ def test_chamfer():
     dl, dr = O.dist_chamfer(a["a"], a["b"])
     assert rel_mse(dl, a["dl"]) < TOL and rel_mse(dr, a["dr"]) < TOL
     assert rel_mse(O.chamfer_cd(a["a"], a["b"]), a["cd"]) < TOL
+
+
+def test_checkpoint_ema_weights_reproduce_reference_sample():
+    """a3 / (f)3: the oracle fed the checkpoint's EMA tensors (optimizer state, keyed by parameter position) gives the
+    sample the reference produced after `resume` + `sample`; fed the raw weights it gives the other recorded one."""
+    import os
+    from conftest import GOLDEN
+    ck = torch.load(os.path.join(GOLDEN, "checkpoint_tiny.pth"), map_location="cpu", weights_only=False)
+    a, _ = load_golden("checkpoint_tiny_expect")
+    cfg = ck["cfg"]
+    assert int(a["epoch_after_resume"]) == ck["epoch"] + 1 and int(a["itr"]) == ck["itr"]
+    raw = ck["score_state_dict"]
+    st = ck["score_optim_state_dict"]["state"]
+    names = [k for k in raw]                                       # state_dict order == parameter order (no buffers)
+    assert len(st) == len(names) == int(a["n_params"])
+    ema = {n: st[i]["ema"] for i, n in enumerate(names)}
+    for n in names:
+        assert ema[n].shape == raw[n].shape
+    _, eps = O.trainer_sample(ema, ck["compressor_state_dict"], cfg, a["x0"], list(a["noises"]))
+    _, eps_raw = O.trainer_sample(raw, ck["compressor_state_dict"], cfg, a["x0"], list(a["noises"]))
+    assert rel_mse(eps, a["eps"]) < 1e-8
+    assert rel_mse(eps_raw, a["eps_raw_weights"]) < 1e-8
+    assert rel_mse(a["eps"], a["eps_raw_weights"]) > 5e-3          # the two are clearly distinguishable
