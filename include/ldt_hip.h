@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 4
+#define LDT_ABI_VERSION 5
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -109,8 +109,11 @@ int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, 
  *   The reference calls pointnet2_ops.furthest_point_sample (Compressor/layers.py:106; third party, not vendored).
  * ldt_knn: k nearest points of each of the S centres by square_distance (layers.py:65-84) + topk(largest=False,
  *   sorted=False) (:97): an UNORDERED index set [B][S][k]; dist_out (nullable) receives the [B][S][n] distances.
- * ldt_group_normalize: LocalGrouper 'anchor' normalisation (:297-315): per-sample unbiased std of (g - anchor)
- *   (stats: fp64 scratch [2*B]), rows U[b,s,j,:] = [alpha*(g-anchor)/(std+1e-5)+beta | centre feature], bf16, K padded to ldu.
+ * ldt_group_normalize: LocalGrouper normalisation (:297-315): per-sample unbiased std of (g - origin)
+ *   (stats: fp64 scratch [2*B]), rows U[b,s,j,:] = [alpha*(g-origin)/(std+1e-5)+beta | centre feature], bf16, K padded to ldu.
+ *   center_mode 0 = 'anchor' (origin = the centre point's [feature|xyz], :309-311; the Compressor, cluster_norm),
+ *   1 = 'center' (origin = mean over the group's k rows, :307-308; ConditionNet, model/scorenet/score.py:22) with
+ *   group_mean an fp32 workspace [B][S][D+3] (may be NULL in mode 0).
  * ldt_gather_rows: index_points (:46-62), out[b,s,:] = src[b, idx[b,s], :].
  * ldt_maxpool: max over the middle axis of [G][n][C] (bf16 or fp32 input) -> fp32 [G][C] (:186, Network.py:97).
  * ldt_actnorm: in place (x - shift[t,c]) * exp(-log_scale[t,c]) (model/layers.py:103-107, eval).
@@ -122,7 +125,8 @@ int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_
             int32_t* idx_out, float* dist_out, void* stream);
 int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,
                         const float* alpha, const float* beta, double* stats, int32_t B, int32_t n, int32_t S,
-                        int32_t k, int32_t D, uint16_t* U, int32_t ldu, void* stream);
+                        int32_t k, int32_t D, uint16_t* U, int32_t ldu, int32_t center_mode, float* group_mean,
+                        void* stream);
 int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream);
 int ldt_maxpool(const void* in, int32_t in_bf16, int64_t ld, int64_t G, int32_t n, int32_t C, float* out, void* stream);
 int ldt_actnorm(float* x, const float* shift, const float* log_scale, int64_t B, int64_t per_sample, void* stream);

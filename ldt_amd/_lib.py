@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -54,7 +54,7 @@ SIGNATURES = {
     "ldt_philox_normal": [_vp, _i64, _i64, _i32, _u64, _vp],
     "ldt_fps": [_vp, _i32, _i32, _i32, _vp, _vp],
     "ldt_knn": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
-    "ldt_group_normalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "ldt_group_normalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "ldt_gather_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_maxpool": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp],
     "ldt_actnorm": [_vp, _vp, _vp, _i64, _i64, _vp],

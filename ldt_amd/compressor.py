@@ -49,16 +49,47 @@ class PreExtraction(_Holder):
 
 
 class LocalGrouper(_Holder):
-    """model/Compressor/layers.py:271-287 (use_xyz=True)."""
+    """model/Compressor/layers.py:271-287 (use_xyz=True): 'anchor' (Compressor, cluster_norm) or 'center'
+    (ConditionNet, model/scorenet/score.py:22) normalisation."""
 
     def __init__(self, in_channels, use_xyz=True, normalize="anchor"):
         super().__init__()
-        if not use_xyz or normalize is None or normalize.lower() != "anchor":
-            raise NotImplementedError("LocalGrouper: only use_xyz=True, normalize='anchor' (shipped cluster_norm) is built")
-        self.normalize = "anchor"
+        if not use_xyz or normalize is None or normalize.lower() not in ("anchor", "center"):
+            raise NotImplementedError("LocalGrouper: only use_xyz=True with normalize 'anchor' or 'center' is built")
+        self.in_channels = in_channels
+        self.normalize = normalize.lower()
         self.affine_alpha = nn.Parameter(torch.ones([1, 1, 1, in_channels + 3]))
         self.affine_beta = nn.Parameter(torch.zeros([1, 1, 1, in_channels + 3]))
         self.extraction = PreExtraction(in_channels, in_channels)
+
+    def pack(self):
+        """fp32 affine vectors + bf16 PreExtraction panels with eval-mode BatchNorm folded into the preceding 1x1 conv
+        (Compressor/layers.py:115-160)."""
+        f32 = lambda t: t.detach().float().contiguous()
+        ex = self.extraction
+        G = {"normalize": self.normalize, "alpha": f32(self.affine_alpha.reshape(-1)), "beta": f32(self.affine_beta.reshape(-1))}
+        w1, b1 = _fold_bn(ex.transfer.net[0], ex.transfer.net[1])
+        G["w_pre1"], G["b_pre1"] = _bf16_panel(w1), b1
+        w2, b2 = _fold_bn(ex.operation[0].net1[0], ex.operation[0].net1[1])
+        G["w_pre2"], G["b_pre2"] = _bf16_panel(w2), b2
+        G["w_pre3"], G["b_pre3"] = _bf16_panel(f32(conv_w(ex.operation[0].net2[0]))), f32(ex.operation[0].net2[0].bias)
+        return G
+
+
+def run_grouper(G, pts, feat, groups, k):
+    """LocalGrouper.forward (Compressor/layers.py:288-319) on the HIP kernels.  pts fp32 [B,n,3], feat fp32 [B,n,D]
+    -> (centres [B,S,3], tokens fp32 [B*S, D], fps_idx, knn_idx): FPS + kNN grouping, normalisation, PreExtraction
+    (Conv+BN+ReLU, residual Conv+BN+ReLU / Conv, ReLU) and the max over the k neighbours."""
+    from ._lib import EPI_RELU_BF16
+    B = pts.shape[0]
+    fps_idx = ops.fps(pts, groups)
+    centers = ops.gather_rows(pts, fps_idx)                                     # [B,S,3]
+    knn_idx = ops.knn(pts, centers, k)
+    U = ops.group_normalize(feat, pts, fps_idx, knn_idx, G["alpha"], G["beta"], normalize=G["normalize"])
+    h1 = ops.gemm_bf16(U, G["w_pre1"], G["b_pre1"], EPI_RELU_BF16)              # transfer: Conv+BN+ReLU
+    r = ops.gemm_bf16(h1, G["w_pre2"], G["b_pre2"], EPI_RELU_BF16)              # net1: Conv+BN+ReLU
+    h2 = ops.gemm_bf16(r, G["w_pre3"], G["b_pre3"], EPI_RELU_BF16, skip=h1)     # act(net2(.) + x)
+    return centers, ops.maxpool(h2, B * groups, k), fps_idx, knn_idx            # max over the k neighbours
 
 
 class MiniPointnet(_Holder):
@@ -175,15 +206,7 @@ class Compressor(nn.Module):
             P["w_out"], P["b_out"] = f32(conv_w(self.output)), f32(self.output.bias)
             P["w_input"], P["b_input"] = f32(conv_w(self.input)), f32(self.input.bias)
             P["prior"] = f32(self.init_set.prior)
-            # LocalGrouper: eval-mode BatchNorm folded into the preceding 1x1 conv (Compressor/layers.py:115-160)
-            ex = self.group.extraction
-            D = self.hidden_dim
-            P["alpha"], P["beta"] = f32(self.group.affine_alpha.reshape(-1)), f32(self.group.affine_beta.reshape(-1))
-            w1, b1 = _fold_bn(ex.transfer.net[0], ex.transfer.net[1])
-            P["w_pre1"], P["b_pre1"] = _bf16_panel(w1), b1
-            w2, b2 = _fold_bn(ex.operation[0].net1[0], ex.operation[0].net1[1])
-            P["w_pre2"], P["b_pre2"] = _bf16_panel(w2), b2
-            P["w_pre3"], P["b_pre3"] = _bf16_panel(f32(conv_w(ex.operation[0].net2[0]))), f32(ex.operation[0].net2[0].bias)
+            P["group"] = self.group.pack()
             # MiniPointnet (Network.py:86-101), fp32
             pe = self.pos_embedding
             P["w_pe1"], P["b_pe1"] = _fold_bn(pe.conv1, pe.bn1)
@@ -260,7 +283,6 @@ class Compressor(nn.Module):
         reconstruction 'set' (B, N, 3).  `post_noise`: optional list of n_layers tensors (B, tokens, z_dim) replacing
         the N(0,1) draws of `sample(mu, logvar)` (Network.py:26-29).  Training-only entries of the reference dict
         ('kls', 'all_logqz') are not produced; 'posteriors' holds token-major (mu, logvar) when want_stats."""
-        from ._lib import ACT_RELU, EPI_RELU_BF16
         if label is not None:
             raise NotImplementedError("class-conditional Compressor is not on the shipped path")
         dev = self._device()
@@ -279,14 +301,7 @@ class Compressor(nn.Module):
         k = N // T * 2                                                              # Network.py:195
         # ---- bottom_up: input conv, FPS + kNN grouping, PreExtraction, pos embedding, ActNorm, encoder stages
         feat = ops.sgemm(pts.view(B * N, 3), P["w_input"], P["b_input"])            # Conv1d 3 -> D  (:192)
-        fps_idx = ops.fps(pts, T)
-        centers = ops.gather_rows(pts, fps_idx)                                     # [B,T,3]
-        knn_idx = ops.knn(pts, centers, k)
-        U = ops.group_normalize(feat.view(B, N, D), pts, fps_idx, knn_idx, P["alpha"], P["beta"])
-        h1 = ops.gemm_bf16(U, P["w_pre1"], P["b_pre1"], EPI_RELU_BF16)              # transfer: Conv+BN+ReLU
-        r = ops.gemm_bf16(h1, P["w_pre2"], P["b_pre2"], EPI_RELU_BF16)              # net1: Conv+BN+ReLU
-        h2 = ops.gemm_bf16(r, P["w_pre3"], P["b_pre3"], EPI_RELU_BF16, skip=h1)     # act(net2(.) + x)
-        tok = ops.maxpool(h2, B * T, k)                                             # max over the k neighbours
+        centers, tok, fps_idx, knn_idx = run_grouper(P["group"], pts, feat.view(B, N, D), T, k)
         tok_pre = tok.clone() if want_stats else None
         c1 = ops.sgemm(centers.view(B * T, 3), P["w_pe1"], P["b_pe1"], act_out=ACT_RELU)
         c2 = ops.sgemm(c1, P["w_pe2"], P["b_pe2"], act_out=ACT_RELU)

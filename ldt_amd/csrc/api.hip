@@ -113,9 +113,11 @@ extern "C" int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_
 }
 extern "C" int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,
                                    const float* alpha, const float* beta, double* stats, int32_t B, int32_t n, int32_t S,
-                                   int32_t k, int32_t D, uint16_t* U, int32_t ldu, void* stream) {
+                                   int32_t k, int32_t D, uint16_t* U, int32_t ldu, int32_t center_mode, float* group_mean,
+                                   void* stream) {
     LDT_REQUIRE(feat && xyz && fps_idx && knn_idx && alpha && beta && stats && U, LDT_EARG, "group: null pointer");
-    return ldt_group_launch(feat, xyz, fps_idx, knn_idx, alpha, beta, stats, B, n, S, k, D, BFM(U), ldu, ST(stream));
+    return ldt_group_launch(feat, xyz, fps_idx, knn_idx, alpha, beta, stats, B, n, S, k, D, BFM(U), ldu, center_mode, group_mean,
+                            ST(stream));
 }
 extern "C" int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream) {
     LDT_REQUIRE(src && idx && out, LDT_EARG, "gather_rows: null pointer");

@@ -180,8 +180,37 @@ int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, 
 //  (2) rows U[b,s,j,:] = [ alpha*(g - anchor)/(std+1e-5) + beta | centre feature ] as bf16, K-padded for the
 //      MFMA GEMM of PreExtraction (:315, :178-187).
 // feat [B*n, D] fp32 (input conv), xyz [B*n, 3]; fps_idx [B,S], knn_idx [B,S,k] int32.
+// 'center' mode: gmean[b,s,c] = mean over the k neighbours of the grouped row [feature | xyz]   (layers.py:307-308)
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                         const int* __restrict__ knn_idx, int n, int S, int k, int D,
+                                                         float* __restrict__ gmean) {
+    const int b = blockIdx.y;
+    const long total = (long)S * (D + 3);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int sidx = (int)(i / (D + 3)), c = (int)(i % (D + 3));
+        const int* nb = knn_idx + ((long)b * S + sidx) * k;
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const long pi = (long)b * n + nb[j];
+            acc += c < D ? feat[pi * D + c] : xyz[pi * 3 + (c - D)];
+        }
+        gmean[((long)b * S + sidx) * (D + 3) + c] = acc / (float)k;
+    }
+}
+
+// The value a grouped element is measured from: the centre point's own [feature | xyz] ('anchor', layers.py:309-311)
+// or the group's mean ('center').
+template <bool CENTER>
+__device__ __forceinline__ float group_origin(const float* __restrict__ fa, const float* __restrict__ xyz_a,
+                                              const float* __restrict__ gm, int c, int D) {
+    if (CENTER) return gm[c];
+    return c < D ? fa[c] : xyz_a[c - D];
+}
+
+template <bool CENTER>
 __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
                                                           const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
+                                                          const float* __restrict__ gmean,
                                                           int n, int S, int k, int D, double* __restrict__ stats) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -193,11 +222,11 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
         const int pi = knn_idx[((long)b * S + sidx) * k + (r % k)];
         const float* fg = feat + ((long)b * n + pi) * D;
         const float* fa = feat + ((long)b * n + ci) * D;
+        const float* xa = xyz + ((long)b * n + ci) * 3;
+        const float* gm = CENTER ? gmean + ((long)b * S + sidx) * (D + 3) : nullptr;
         for (int c = lane; c < D + 3; c += 64) {
-            float g, a;
-            if (c < D) { g = fg[c]; a = fa[c]; }
-            else { g = xyz[((long)b * n + pi) * 3 + (c - D)]; a = xyz[((long)b * n + ci) * 3 + (c - D)]; }
-            const float d = g - a;
+            const float g = c < D ? fg[c] : xyz[((long)b * n + pi) * 3 + (c - D)];
+            const float d = g - group_origin<CENTER>(fa, xa, gm, c, D);
             s1 += (double)d; s2 += (double)d * (double)d;
         }
     }
@@ -206,11 +235,12 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
     if (lane == 0) { atomicAdd(&stats[2 * b], s1); atomicAdd(&stats[2 * b + 1], s2); }
 }
 
+template <bool CENTER>
 __global__ __launch_bounds__(256) void group_build_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
                                                           const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
                                                           const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                          const double* __restrict__ stats, int n, int S, int k, int D,
-                                                          bf16_t* __restrict__ U, int ldu) {
+                                                          const double* __restrict__ stats, const float* __restrict__ gmean,
+                                                          int n, int S, int k, int D, bf16_t* __restrict__ U, int ldu) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const long rows = (long)S * k;
@@ -224,14 +254,14 @@ __global__ __launch_bounds__(256) void group_build_kernel(const float* __restric
         const int pi = knn_idx[((long)b * S + sidx) * k + (r % k)];
         const float* fg = feat + ((long)b * n + pi) * D;
         const float* fa = feat + ((long)b * n + ci) * D;
+        const float* xa = xyz + ((long)b * n + ci) * 3;
+        const float* gm = CENTER ? gmean + ((long)b * S + sidx) * (D + 3) : nullptr;
         bf16_t* u = U + ((long)b * rows + r) * ldu;
         for (int c = lane; c < ldu; c += 64) {
             float v = 0.f;
             if (c < D + 3) {
-                float g, a;
-                if (c < D) { g = fg[c]; a = fa[c]; }
-                else { g = xyz[((long)b * n + pi) * 3 + (c - D)]; a = xyz[((long)b * n + ci) * 3 + (c - D)]; }
-                v = alpha[c] * ((g - a) * inv) + beta[c];
+                const float g = c < D ? fg[c] : xyz[((long)b * n + pi) * 3 + (c - D)];
+                v = alpha[c] * ((g - group_origin<CENTER>(fa, xa, gm, c, D)) * inv) + beta[c];
             } else if (c < 2 * D + 3) {
                 v = fa[c - (D + 3)];
             }
@@ -241,15 +271,26 @@ __global__ __launch_bounds__(256) void group_build_kernel(const float* __restric
 }
 
 int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
-                     const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu, hipStream_t s) {
+                     const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu,
+                     int center_mode, float* gmean, hipStream_t s) {
     LDT_REQUIRE(B > 0 && n > 0 && S > 0 && k > 0 && D > 0 && ldu >= 2 * D + 3, LDT_ESHAPE, "group: bad shape");
+    LDT_REQUIRE(center_mode == 0 || (center_mode == 1 && gmean), LDT_EARG, "group: mode 1 ('center') needs the group-mean workspace");
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s);
     if (e != hipSuccess) { ldt_set_error("group: memset: %s", hipGetErrorString(e)); return (int)e; }
     const long rows = (long)S * k;
     int bx = (int)((rows + 3) / 4); if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(group_stats_kernel, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, D, stats);
+    if (center_mode) {
+        long mb = ((long)S * (D + 3) + 255) / 256; if (mb > 1024) mb = 1024;
+        hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)mb, B), dim3(256), 0, s, feat, xyz, knn_idx, n, S, k, D, gmean);
+        TRY_LAUNCH("group_mean");
+        hipLaunchKernelGGL(group_stats_kernel<true>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, gmean, n, S, k, D, stats);
+        TRY_LAUNCH("group_stats");
+        hipLaunchKernelGGL(group_build_kernel<true>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, gmean, n, S, k, D, U, ldu);
+        return ldt_check_launch("group_build");
+    }
+    hipLaunchKernelGGL(group_stats_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, nullptr, n, S, k, D, stats);
     TRY_LAUNCH("group_stats");
-    hipLaunchKernelGGL(group_build_kernel, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, n, S, k, D, U, ldu);
+    hipLaunchKernelGGL(group_build_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, nullptr, n, S, k, D, U, ldu);
     return ldt_check_launch("group_build");
 }
 

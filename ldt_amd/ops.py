@@ -165,15 +165,17 @@ def knn(xyz, centers, k, return_dist=False):
     return (idx, dist) if return_dist else idx
 
 
-def group_normalize(feat, xyz, fps_idx, knn_idx, alpha, beta):
-    """LocalGrouper 'anchor' rows: -> bf16 [B*S*k, pad64(2D+3)]."""
+def group_normalize(feat, xyz, fps_idx, knn_idx, alpha, beta, normalize="anchor"):
+    """LocalGrouper rows ('anchor' or 'center' normalisation): -> bf16 [B*S*k, pad64(2D+3)]."""
     B, n, D = feat.shape
     S, k = knn_idx.shape[1], knn_idx.shape[2]
     ldu = pad64(2 * D + 3)
     U = torch.empty((B * S * k, ldu), dtype=torch.bfloat16, device=feat.device)
     stats = torch.empty((2 * B,), dtype=torch.float64, device=feat.device)
+    mode = {"anchor": 0, "center": 1}[normalize]
+    gmean = torch.empty((B, S, D + 3), dtype=torch.float32, device=feat.device) if mode else None
     check(lib().ldt_group_normalize(_p(feat), _p(xyz), _p(fps_idx), _p(knn_idx), _p(alpha), _p(beta), _p(stats), B, n, S, k, D,
-                                    _p(U), ldu, stream_ptr()), "ldt_group_normalize")
+                                    _p(U), ldu, mode, _p(gmean), stream_ptr()), "ldt_group_normalize")
     return U
 
 

@@ -41,12 +41,8 @@ class Score(nn.Module):
         self.unet = cfg.unet
         self.AdaLN = cfg.AdaLN
         if self.condition:
-            # ConditionNet (score.py:13-44) wraps a torchvision resnet18 trunk + a LocalGrouper; it runs ONCE per
-            # sample() call, outside the loop.  Its parameters are not built here: pass the already-embedded
-            # condition tuple (pts_condition (B,hidden,S) or None, img_condition (B,t_dim) or 0.) to forward().
-            raise NotImplementedError("cfg.score.condition=True builds ConditionNet (torchvision resnet18), which is not part "
-                                      "of this path; construct Score with condition=False and pass the embedded "
-                                      "condition tuple to forward(..., condition=(pts_cond, img_cond))")
+            from .condition import ConditionNet                     # built first, as upstream (score.py:64-65)
+            self.c_net = ConditionNet(self.hidden_size, self.t_dim, patch_size=self.z_scale)
         if self.unet:
             raise NotImplementedError("unet: True Score variant (score.py:67-83) is not on the shipped path")
         if not self.AdaLN or getattr(cfg, "dropout", 0.):
@@ -125,8 +121,10 @@ class Score(nn.Module):
 
     def condition_embedding(self, label=None, condition=None):
         """-> (extra [B,t_dim] or None, kv_cond {block: K|V} or None, cond_tokens) for forward()/the fused loop."""
-        if isinstance(condition, dict):
-            raise NotImplementedError("raw ViPC condition dicts need ConditionNet (resnet18 trunk); pass its output tuple")
+        if isinstance(condition, dict):                              # score.py:129-131: raw ViPC inputs -> ConditionNet
+            if not hasattr(self, "c_net"):
+                raise ValueError("a raw condition dict needs cfg.score.condition=True (ConditionNet, score.py:64-65)")
+            condition = self.c_net(condition)
         pts_cond, img_cond = (None, 0.) if condition is None else condition
         extra = None
         if label is not None:
@@ -248,7 +246,8 @@ class Score(nn.Module):
         label: (bs,) class ids (LabelEmbedding, num_categorys > 1).  condition: the EMBEDDED pair the reference's
         ConditionNet returns — (pts_condition (bs, hidden, S) or None, img_condition (bs, t_dim) or 0.) — cross-
         attended on even blocks / added to the time embedding (score.py:135,148-149; a label wins over the image
-        condition by the reference's operator precedence).  A raw dict would need ConditionNet (see __init__)."""
+        condition by the reference's operator precedence).  A raw dict {'img':…, 'pts':…} goes through `self.c_net`
+        (cfg.score.condition=True) first, as upstream (:129-131)."""
         if not x.is_cuda:
             raise RuntimeError("Score.forward: x is on %s; the HIP path has no CPU fallback" % x.device)
         B, T, z = x.shape

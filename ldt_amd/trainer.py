@@ -100,6 +100,8 @@ class Trainer:
                     label = _rows(label, lo, hi, per)
                 if isinstance(condition, (tuple, list)):
                     condition = tuple(_rows(c, lo, hi, per) if torch.is_tensor(c) else c for c in condition)
+                elif isinstance(condition, dict):        # raw ViPC inputs {'img','pts'}: ConditionNet runs on this rank's rows
+                    condition = {k: _rows(v, lo, hi, per) if torch.is_tensor(v) else v for k, v in condition.items()}
             eps = self.SDE.sample_discrete(score_fn=self.score_fn, N=self.cfg.sde.sample_N,
                                            corrector=self.cfg.sde.corrector, predictor=self.cfg.sde.predictor,
                                            corrector_steps=self.cfg.sde.corrector_steps, shape=shape,

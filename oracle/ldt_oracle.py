@@ -366,8 +366,8 @@ def batch_norm_eval(sd, prefix, x):
                         sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, 1e-5).reshape(x.shape)
 
 
-def local_grouper(sd, prefix, xyz, feat, groups, k, fps_idx=None, knn_idx=None):
-    """model/Compressor/layers.py:288-319 (normalize='anchor', use_xyz=True).
+def local_grouper(sd, prefix, xyz, feat, groups, k, fps_idx=None, knn_idx=None, normalize="anchor"):
+    """model/Compressor/layers.py:288-319 (normalize='anchor' or 'center', use_xyz=True).
     xyz [B,N,3], feat [B,N,D] -> centres [B,S,3], tokens [B,S,D]; also returns the index sets."""
     B, N, _ = xyz.shape
     if fps_idx is None:
@@ -377,7 +377,10 @@ def local_grouper(sd, prefix, xyz, feat, groups, k, fps_idx=None, knn_idx=None):
         knn_idx = knn(k, xyz, new_xyz)                              # :111
     new_feat = gather(feat, fps_idx)                                # :299
     g = torch.cat([gather(feat, knn_idx), gather(xyz, knn_idx)], dim=-1)     # :301-304  [B,S,k,D+3]
-    mean = torch.cat([new_feat, new_xyz], dim=-1).unsqueeze(-2)     # :308-310 anchor
+    if normalize == "center":
+        mean = torch.mean(g, dim=2, keepdim=True)                   # :306-307
+    else:
+        mean = torch.cat([new_feat, new_xyz], dim=-1).unsqueeze(-2)  # :308-310 anchor
     std = torch.std((g - mean).reshape(B, -1), dim=-1, keepdim=True)[..., None, None]  # :311-312 unbiased
     g = (g - mean) / (std + 1e-5)                                   # :313
     g = sd[prefix + ".affine_alpha"] * g + sd[prefix + ".affine_beta"]       # :314
@@ -390,6 +393,46 @@ def local_grouper(sd, prefix, xyz, feat, groups, k, fps_idx=None, knn_idx=None):
     h = F.relu(r + h)
     tokens = h.max(dim=2)[0]                                        # adaptive_max_pool1d over k
     return new_xyz, tokens, fps_idx, knn_idx
+
+
+def condition_net_points(sd, prefix, pts, patch_size, fps_idx=None, knn_idx=None):
+    """ConditionNet point branch (model/scorenet/score.py:20-23,37-41): Conv1d 3->128, LocalGrouper(128, 'center')
+    into `patch_size` groups of k = 128 // patch_size * 2 neighbours (`x.shape[1]` there is the CHANNEL count 128,
+    :40), Conv1d 128->hidden.  pts [B,N,3] -> pts_condition token-major [B,S,hidden] (reference: (B,hidden,S))."""
+    x = linear(sd, prefix + ".pc_conv_in", pts)
+    k = x.shape[-1] // patch_size * 2
+    _, tok, fps_idx, knn_idx = local_grouper(sd, prefix + ".group", pts, x, patch_size, k, fps_idx, knn_idx,
+                                             normalize="center")
+    return linear(sd, prefix + ".pc_conv_out", tok), fps_idx, knn_idx
+
+
+def _bn2d(sd, prefix, x, eps=1e-5):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], False, 0.0, eps)
+
+
+def _basic_block(sd, prefix, x, stride):
+    """torchvision BasicBlock: conv3x3(stride) BN ReLU conv3x3 BN (+ 1x1-conv/BN downsample of the input) ReLU."""
+    h = F.relu(_bn2d(sd, prefix + ".bn1", F.conv2d(x, sd[prefix + ".conv1.weight"], None, stride, 1)))
+    h = _bn2d(sd, prefix + ".bn2", F.conv2d(h, sd[prefix + ".conv2.weight"], None, 1, 1))
+    if prefix + ".downsample.0.weight" in sd:
+        x = _bn2d(sd, prefix + ".downsample.1", F.conv2d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0))
+    return F.relu(h + x)
+
+
+def condition_net_image(sd, prefix, img):
+    """ConditionNet image branch (score.py:24-27,33-36): the first six children of torchvision's resnet18
+    (conv1 7x7/2, bn1, relu, maxpool 3x3/2, layer1 = 2 BasicBlocks(64), layer2 = 2 BasicBlocks(128, first stride 2)),
+    global max pool, Linear 128 -> p_dim.  torchvision is ABSENT from this image: the trunk is restated from its
+    published architecture, PARITY UNPINNED; eval-mode BatchNorm.  img [B,3,H,W] -> [B,p_dim]."""
+    r = prefix + ".resnet"
+    h = F.relu(_bn2d(sd, r + ".1", F.conv2d(img, sd[r + ".0.weight"], None, 2, 3)))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for layer, stride in ((4, 1), (5, 2)):
+        for blk in (0, 1):
+            h = _basic_block(sd, "%s.%d.%d" % (r, layer, blk), h, stride if blk == 0 else 1)
+    h = F.adaptive_max_pool2d(h, 1).flatten(1)            # .squeeze() upstream (drops the batch axis too when B == 1)
+    return linear(sd, prefix + ".ln", h)
 
 
 def mini_pointnet(sd, prefix, centers):

@@ -141,10 +141,8 @@ def test_product_never_imports_oracle():
 def test_unsupported_options_raise(tiny_cfg):
     import copy
     import ldt_amd
-    c = copy.deepcopy(tiny_cfg)
-    c.score.condition = True                      # would build ConditionNet (torchvision resnet18)
-    with pytest.raises(NotImplementedError):
-        ldt_amd.Score(c.score)
+    with pytest.raises(ValueError):                # a raw condition dict without cfg.score.condition=True
+        ldt_amd.Score(tiny_cfg.score).condition_embedding(None, {"pts": torch.zeros(1, 96, 3)})
     c = copy.deepcopy(tiny_cfg)
     c.score.unet = True
     with pytest.raises(NotImplementedError):
@@ -214,3 +212,30 @@ def test_resume_reads_reference_checkpoint_layout():
         assert (tr2.epoch, tr2.itr) == (1, 0)
     finally:
         shutil.rmtree(d)
+
+
+def test_condition_net_parameter_tree(tiny_cfg):
+    """(f)1: ConditionNet's state_dict carries the reference's names — the point branch as captured from the reference
+    module, the image trunk under torchvision resnet18's child indices (score.py:25-26: children()[:-4])."""
+    import copy
+    import ldt_amd
+    a, sds = load_golden("condition_net_pts")
+    net = ldt_amd.ConditionNet(int(a["hidden"]), int(a["p_dim"]), patch_size=int(a["patch_size"]), img_condition=False)
+    assert sorted(net.state_dict()) == sorted(sds["w"])
+    for k, v in sds["w"].items():
+        assert tuple(net.state_dict()[k].shape) == tuple(v.shape), k
+    full = ldt_amd.ConditionNet(128, 64, patch_size=8)
+    names = set(full.state_dict())
+    for k in ("resnet.0.weight", "resnet.1.running_var", "resnet.4.0.conv1.weight", "resnet.4.1.bn2.bias",
+              "resnet.5.0.downsample.0.weight", "resnet.5.0.downsample.1.running_mean", "resnet.5.1.conv2.weight",
+              "ln.weight", "conv_out.weight", "pc_conv_in.weight", "group.affine_alpha"):
+        assert k in names, k
+    assert not any(k.startswith(("resnet.6", "resnet.7", "resnet.4.0.downsample")) for k in names)
+    assert full.state_dict()["resnet.0.weight"].shape == (64, 3, 7, 7)
+    assert full.state_dict()["resnet.5.0.conv1.weight"].shape == (128, 64, 3, 3) and full.state_dict()["ln.weight"].shape == (64, 128)
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.condition = True
+    score = ldt_amd.Score(cfg.score)
+    assert list(score.state_dict())[0].startswith("c_net.")            # built before the Transformer, as upstream
+    with pytest.raises(RuntimeError):
+        score.c_net({"pts": torch.zeros(1, 96, 3)})                    # CPU tensors/params: no fallback

@@ -213,3 +213,18 @@ def test_checkpoint_ema_weights_reproduce_reference_sample():
     assert rel_mse(eps, a["eps"]) < 1e-8
     assert rel_mse(eps_raw, a["eps_raw_weights"]) < 1e-8
     assert rel_mse(a["eps"], a["eps_raw_weights"]) > 5e-3          # the two are clearly distinguishable
+
+
+def test_condition_net_point_branch():
+    """(f)1: ViPC ConditionNet point branch (score.py:37-41; LocalGrouper normalize='center') vs the reference."""
+    a, sds = load_golden("condition_net_pts")
+    sd = {"c_net." + k: v for k, v in sds["w"].items()}
+    out, fi, ki = O.condition_net_points(sd, "c_net", a["pts"], int(a["patch_size"]))
+    assert int(a["k"]) == 128 // int(a["patch_size"]) * 2          # k comes from the CHANNEL count (score.py:40)
+    assert torch.equal(fi, a["fps_idx"])
+    assert torch.equal(ki.sort(-1)[0], a["knn_idx"].sort(-1)[0])
+    assert rel_mse(out, a["pts_condition"].transpose(1, 2)) < TOL
+    # 'anchor' normalisation would give a different answer: the mode is exercised
+    x = O.linear(sd, "c_net.pc_conv_in", a["pts"])
+    _, tok, _, _ = O.local_grouper(sd, "c_net.group", a["pts"], x, int(a["patch_size"]), int(a["k"]), normalize="anchor")
+    assert rel_mse(O.linear(sd, "c_net.pc_conv_out", tok), a["pts_condition"].transpose(1, 2)) > 1e-3
