@@ -22,10 +22,10 @@ def _bf(w):
 
 def pack_block(blk):
     """bf16 operand panels + fp32 vectors of one ResidualBlock holder."""
-    C = blk.dim_in
+    C, Co = blk.dim_in, blk.dim_out
     wkv = conv_w(blk.fc_kv)
     P = {
-        "C": C, "H": blk.num_heads,
+        "C": C, "Co": Co, "H": blk.num_heads,
         "wq": _bf(conv_w(blk.fc_q)), "bq": blk.fc_q.bias.detach().float().contiguous(),
         "wkv": _bf(wkv), "bkv": blk.fc_kv.bias.detach().float().contiguous(),
         "wo": _bf(conv_w(blk.fc_o)), "bo": blk.fc_o.bias.detach().float().contiguous(),
@@ -34,37 +34,53 @@ def pack_block(blk):
         "n1": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm1.affine),
         "n2": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm2.affine),
     }
-    if blk.dim_c is not None:
+    if blk.dim_c is not None and C == Co:
         lin = blk.adaLN[1]
         P["wada"], P["bada"] = lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
+    elif blk.dim_c is not None:                                      # U-Net down block: two adaLN heads + conv shortcut
+        P["wada1"], P["bada1"] = (t.detach().float().contiguous() for t in (blk.adaLN1[1].weight, blk.adaLN1[1].bias))
+        P["wada2"], P["bada2"] = (t.detach().float().contiguous() for t in (blk.adaLN2[1].weight, blk.adaLN2[1].bias))
+        P["wsc"], P["bsc"] = _bf(conv_w(blk.shortcut)), blk.shortcut.bias.detach().float().contiguous()
     return P
 
 
 def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
-    """x fp32 [B*Nq, C] updated IN PLACE.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
+    """x fp32 [B*Nq, C] updated IN PLACE (and returned) when dim_out == dim_in; a NEW [B*Nq, dim_out] tensor is returned
+    for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
     c: fp32 [B, dim_c] condition (AdaLN) or None (affine LayerNorm block)."""
-    C, H = P["C"], P["H"]
-    if c is not None:
+    C, Co, H = P["C"], P["Co"], P["H"]
+    if c is not None and C == Co:
         mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                  # [B, 6C]  layers.py:214
         sh1, sc1, g1, sh2, sc2, g2 = (mod[:, i * C:(i + 1) * C] for i in range(6))
-        h = ops.layernorm_modulate(x, shift=sh1, scale=sc1, mod_sample_stride=6 * C, rows_per_sample=Nq)
+        s1 = s2 = 6 * C
+        h = ops.layernorm_modulate(x, shift=sh1, scale=sc1, mod_sample_stride=s1, rows_per_sample=Nq)
+    elif c is not None:                                                             # layers.py:216-217
+        m1 = ops.sgemm(c, P["wada1"], P["bada1"], act_in=ACT_SILU)                 # [B, 2C]   shift_msa | scale_msa
+        mod = ops.sgemm(c, P["wada2"], P["bada2"], act_in=ACT_SILU)                # [B, 4Co]  gate_msa | shift_mlp | scale_mlp | gate_mlp
+        g1, sh2, sc2, g2 = (mod[:, i * Co:(i + 1) * Co] for i in range(4))
+        s2 = 4 * Co
+        h = ops.layernorm_modulate(x, shift=m1[:, :C], scale=m1[:, C:], mod_sample_stride=2 * C, rows_per_sample=Nq)
     else:
         g1 = g2 = None
+        s2 = 0
         h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
     q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
     if y_bf16 is None:
         y_bf16, Nk = h, Nq
-    kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                        # [B*Nk, 2C]: K | V  (layers.py:189)
-    a = ops.attention_fwd(q, kv[:, :C], kv[:, C:], B, H, Nq, Nk, C // H)            # [B,H,Nq,Dh] == (B*Nq, C) raw view
-    ops.gemm_bf16(a.view(B * Nq, C), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
-                  gate_sample_stride=6 * C if g1 is not None else 0, rows_per_sample=Nq)
+    kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                        # [B*Nk, 2Co]: K | V  (layers.py:189)
+    a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)         # [B,H,Nq,Dh] == (B*Nq, Co) raw view
+    if C != Co:                                                                     # shortcut(x): Conv1d dim_in -> dim_out
+        from ._lib import EPI_F32
+        x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)
+    ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
+                  gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=Nq)
     if c is not None:
-        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=6 * C, rows_per_sample=Nq)
+        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=Nq)
     else:
         h2 = ops.layernorm_modulate(x, w=P["n2"][0], b=P["n2"][1])
     u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
     ops.gemm_bf16(u, P["wdn"], P["bdn"], EPI_RESID_F32, out=x, resid=x, gate=g2,
-                  gate_sample_stride=6 * C if g2 is not None else 0, rows_per_sample=Nq)
+                  gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=Nq)
     return x
 
 

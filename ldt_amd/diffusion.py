@@ -205,6 +205,7 @@ def _fused_model(score_fn):
     from .score import Score
     owner = getattr(score_fn, "__self__", None)
     model = getattr(owner, "model", None)
-    if isinstance(model, Score) and getattr(score_fn, "__func__", None) is getattr(type(owner), "score_fn", None):
-        return model
+    if isinstance(model, Score) and not model.unet \
+            and getattr(score_fn, "__func__", None) is getattr(type(owner), "score_fn", None):
+        return model                                            # (the U-Net variant is driven by the generic loop)
     return None

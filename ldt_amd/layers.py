@@ -78,26 +78,36 @@ class MLP(_Holder):
 
 
 class ResidualBlock(_Holder):
-    """model/layers.py:140-181 with dim_out == dim_in (the Transformer / Compressor use)."""
+    """model/layers.py:140-181.  dim_out == dim_in: the Transformer / Compressor block (one adaLN of 6 chunks, identity
+    shortcut).  dim_out != dim_in: the U-Net "down" block (score.py:77-83) — 1x1-conv shortcut, adaLN1 (shift, scale of
+    width dim_in) and adaLN2 (gate_msa, shift_mlp, scale_mlp, gate_mlp of width dim_out)."""
 
     def __init__(self, dim_in, dim_kv, dim_c, num_heads, norm=None, mlp_ratio=4.0, dropout_att=0., dropout_mlp=0.,
                  rescale=False, dim_out=None, AdaLN=True, act=None):
         super().__init__()
-        if dim_out is not None and dim_out != dim_in:
-            raise NotImplementedError("dim_in != dim_out (U-Net down blocks) is not on the shipped path")
         if rescale or dropout_att or dropout_mlp or (dim_c is not None and not AdaLN):
             raise NotImplementedError("ResidualBlock variant not on the shipped path")
         if act is not None and dim_c is None:
             raise NotImplementedError("no-condition block with an activation (decoder_act) is not built")
-        self.dim_in, self.dim_kv, self.dim_c, self.num_heads = dim_in, dim_kv, dim_c, num_heads
-        self.fc_q = nn.Conv1d(dim_in, dim_in, 1)
-        self.fc_kv = nn.Conv1d(dim_kv, 2 * dim_in, 1)
-        self.fc_o = nn.Conv1d(dim_in, dim_in, 1)
+        if dim_out is not None and dim_out != dim_in:
+            if dim_c is None:
+                raise NotImplementedError("dim_in != dim_out without a condition is not used by the reference")
+            self.shortcut = nn.Conv1d(dim_in, dim_out, 1)
+        else:
+            dim_out = dim_in
+        self.dim_in, self.dim_out, self.dim_kv, self.dim_c, self.num_heads = dim_in, dim_out, dim_kv, dim_c, num_heads
+        self.fc_q = nn.Conv1d(dim_in, dim_out, 1)
+        self.fc_kv = nn.Conv1d(dim_kv, 2 * dim_out, 1)
+        self.fc_o = nn.Conv1d(dim_out, dim_out, 1)
         self.norm1 = make_norm(dim_in, norm, elementwise_affine=dim_c is None)
-        self.norm2 = make_norm(dim_in, norm, elementwise_affine=dim_c is None)
+        self.norm2 = make_norm(dim_out, norm, elementwise_affine=dim_c is None)
         if dim_c is not None:
-            self.adaLN = nn.Sequential(nn.SiLU(), nn.Linear(dim_c, 6 * dim_in))
-        self.mlp = MLP(dim_in, int(mlp_ratio * dim_in), dim_in, 1)
+            if dim_in == dim_out:
+                self.adaLN = nn.Sequential(nn.SiLU(), nn.Linear(dim_c, 6 * dim_out))
+            else:
+                self.adaLN1 = nn.Sequential(nn.SiLU(), nn.Linear(dim_c, 2 * dim_in))
+                self.adaLN2 = nn.Sequential(nn.SiLU(), nn.Linear(dim_c, 4 * dim_out))
+        self.mlp = MLP(dim_out, int(mlp_ratio * dim_out), dim_out, 1)
 
 
 class FinalLayer(_Holder):

@@ -43,15 +43,19 @@ class Score(nn.Module):
         if self.condition:
             from .condition import ConditionNet                     # built first, as upstream (score.py:64-65)
             self.c_net = ConditionNet(self.hidden_size, self.t_dim, patch_size=self.z_scale)
-        if self.unet:
-            raise NotImplementedError("unet: True Score variant (score.py:67-83) is not on the shipped path")
         if not self.AdaLN or getattr(cfg, "dropout", 0.):
             raise NotImplementedError("only AdaLN blocks without dropout are built")
         if self.num_blocks > MAX_BLOCKS:
             raise ValueError("num_blocks > %d" % MAX_BLOCKS)
-        self.Transformer = nn.ModuleList([
-            ResidualBlock(self.hidden_size, self.hidden_size, self.t_dim, self.num_heads, norm=self.norm,
-                          act=cfg.act, AdaLN=self.AdaLN) for _ in range(self.num_blocks)])
+        D = self.hidden_size
+        mk = lambda din, dout=None: ResidualBlock(din, din, self.t_dim, self.num_heads, norm=self.norm, dim_out=dout,
+                                                  act=cfg.act, AdaLN=self.AdaLN)
+        if self.unet:                                               # score.py:67-83: up / mid / down with skip concats
+            self.Transformer_Up = nn.ModuleList([mk(D) for _ in range(self.num_blocks // 2)])
+            self.Transformer_Mid = mk(D)
+            self.Transformer_Down = nn.ModuleList([mk(2 * D, D) for _ in range(self.num_blocks // 2)])
+        else:
+            self.Transformer = nn.ModuleList([mk(D) for _ in range(self.num_blocks)])
         if cfg.num_categorys > 1:
             self.LabelEmbedding = LabelEmbedding(cfg.num_categorys, self.t_dim, self.t_dim)
         else:
@@ -81,6 +85,16 @@ class Score(nn.Module):
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("Score parameters are on %s: the HIP path needs them on the GPU (.to('cuda'))" % dev)
+        if self.unet:
+            from .blocks import pack_block, pack_final
+            with torch.no_grad():
+                zp = ops.pad64(self.z_dim)
+                P = {"w_in": ops.cast_pad_bf16(conv_w(self.ln_in).float().contiguous(), zp),
+                     "b_in": self.ln_in.bias.detach().float().contiguous(),
+                     "up": [pack_block(b) for b in self.Transformer_Up], "mid": pack_block(self.Transformer_Mid),
+                     "down": [pack_block(b) for b in self.Transformer_Down], "final": pack_final(self.ln_out)}
+            self._pack, self._pack_key = P, key
+            return P
         with torch.no_grad():
             P = {"w_qkv": [], "b_qkv": [], "w_o": [], "b_o": [], "w_up": [], "b_up": [], "w_dn": [], "b_dn": []}
             zp = ops.pad64(self.z_dim)
@@ -253,6 +267,8 @@ class Score(nn.Module):
         B, T, z = x.shape
         assert z == self.z_dim
         x = x.contiguous().float()
+        if self.unet:
+            return self._forward_unet(x, t, label, condition)
         extra, kv, S = self.condition_embedding(label, condition)
         _, mod = self.time_table(t.to(x).float(), extra_c=extra)
         plan = self.plan(B, T, mod, 0, self.n_mod, kv_cond=kv, cond_tokens=S)      # per-sample AdaLN rows
@@ -260,3 +276,31 @@ class Score(nn.Module):
         check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), None, ops.stream_ptr()),
               "ldt_score_forward")
         return out
+
+    def _forward_unet(self, x, t, label, condition):
+        """`unet: True` variant (score.py:138-146): num_blocks//2 up blocks whose outputs are kept, a mid block, then
+        num_blocks//2 down blocks on cat(x, skip) (width 2*hidden -> hidden, conv shortcut, adaLN1/adaLN2).  Host-driven:
+        each block is the same sequence of HIP kernels as the Compressor's blocks (ldt_amd/blocks.py)."""
+        from ._lib import EPI_F32
+        from .blocks import final_layer, residual_block
+        pts_cond, img_cond = (None, 0.) if condition is None else (self.c_net(condition) if isinstance(condition, dict) else condition)
+        if torch.is_tensor(pts_cond):
+            raise NotImplementedError("unet + point condition: the reference passes the (B,hidden,S) condition as K/V source to "
+                                      "down blocks whose fc_kv expects 2*hidden channels (score.py:80,146) and fails there")
+        B, T, _ = x.shape
+        P = self.packed()
+        c = self.time_embedding(t.to(x).float())
+        if label is not None:
+            c = c + self.label_embedding(label)
+        elif torch.is_tensor(img_cond):
+            c = c + img_cond.to(x)
+        xin = ops.cast_pad_bf16(x.view(B * T, self.z_dim), ops.pad64(self.z_dim))
+        h = ops.gemm_bf16(xin, P["w_in"], P["b_in"], EPI_F32)                       # ln_in
+        skips = [h.clone()]
+        for Pb in P["up"]:
+            residual_block(Pb, h, B, T, c=c)
+            skips.append(h.clone())
+        residual_block(P["mid"], h, B, T, c=c)
+        for Pb in P["down"]:
+            h = residual_block(Pb, torch.cat((h, skips.pop()), dim=1), B, T, c=c)   # channels: [x | skip]  (:145)
+        return final_layer(P["final"], h, B, T, c).view(B, T, self.z_dim)

@@ -100,14 +100,22 @@ def mlp(sd, prefix, x):
 
 
 def residual_block(sd, prefix, x, y, c, num_heads):
-    """model/layers.py:202-229 (dim_in == dim_out, shortcut = Identity).
+    """model/layers.py:202-229.
 
     c is not None  -> AdaLN branch (:212-219), LayerNorm without affine.
        y is None   -> K/V from the modulated-normalised x (Score, :184-185)
        y given     -> K/V from RAW y (Compressor Encoder passes y=x, quirk Q2)
+       dim_in != dim_out (U-Net down block: `<prefix>.shortcut` exists) -> adaLN1 gives (shift, scale) of width dim_in,
+       adaLN2 gives (gate_msa, shift_mlp, scale_mlp, gate_mlp) of width dim_out, the skip path is the 1x1 conv (:216-218)
     c is None      -> no-condition branch (:224-226), LayerNorm WITH affine, act=Identity
                       (decoder_act: ~ in the shipped config)."""
-    if c is not None:
+    if c is not None and prefix + ".shortcut.weight" in sd:
+        sh1, sc1 = linear(sd, prefix + ".adaLN1.1", F.silu(c))[:, None, :].chunk(2, dim=-1)
+        g1, sh2, sc2, g2 = linear(sd, prefix + ".adaLN2.1", F.silu(c))[:, None, :].chunk(4, dim=-1)
+        h = modulate(layer_norm(x), sh1, sc1)
+        x = linear(sd, prefix + ".shortcut", x) + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
+        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
+    elif c is not None:
         m = linear(sd, prefix + ".adaLN.1", F.silu(c))[:, None, :]      # [B,1,6C]
         sh1, sc1, g1, sh2, sc2, g2 = m.chunk(6, dim=-1)
         h = modulate(layer_norm(x), sh1, sc1)
@@ -132,7 +140,7 @@ def final_layer(sd, prefix, x, c):
 
 
 def score_forward(sd, cfg, x, t, label_emb=None, condition=None, trace=None):
-    """model/scorenet/score.py:117-151 (unet: False path).
+    """model/scorenet/score.py:117-151 (both the plain stack and, when cfg.unet, the up/mid/down variant :138-146).
 
     x [B,T,z], t [B].  condition = (pts_cond [B,S,hidden] token-major or None, img_cond [B,t_dim] or 0.)
     label_emb: already-embedded label [B,t_dim] (LabelEmbedding, layers.py:44-52) — label wins over
@@ -144,6 +152,16 @@ def score_forward(sd, cfg, x, t, label_emb=None, condition=None, trace=None):
     if trace is not None:
         trace.append(("c", c.clone()))
         trace.append(("ln_in", h.clone()))
+    if getattr(cfg, "unet", False):
+        skips = [h]
+        for i in range(cfg.num_blocks // 2):
+            h = residual_block(sd, "Transformer_Up.%d" % i, h, pts_cond, c, cfg.num_heads)      # every layer gets y (:141)
+            skips.append(h)
+        h = residual_block(sd, "Transformer_Mid", h, pts_cond, c, cfg.num_heads)
+        for i in range(cfg.num_blocks // 2):
+            h = torch.cat((h, skips.pop()), dim=-1)                                            # channels [x | skip] (:145)
+            h = residual_block(sd, "Transformer_Down.%d" % i, h, pts_cond, c, cfg.num_heads)
+        return final_layer(sd, "ln_out", h, c)
     for i in range(cfg.num_blocks):
         y = pts_cond if (i % 2 == 0) else None
         h = residual_block(sd, "Transformer.%d" % i, h, y, c, cfg.num_heads)

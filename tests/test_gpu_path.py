@@ -56,7 +56,7 @@ def test_score_forward_conditioned_golden(env):
     only_img = env["score"](a["x"].cuda(), a["t"].cuda(), condition=(None, a["img_cond"].cuda()))
     ref = env["O"].score_forward(env["ssd"], env["cfg"].score, a["x"], a["t"], condition=(None, a["img_cond"]))
     assert rel_mse(only_img.cpu(), ref) < TOL_PARAMS
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                   # raw dicts need cfg.score.condition=True (c_net)
         env["score"](a["x"].cuda(), a["t"].cuda(), condition={"pts": pts})
 
 
@@ -300,3 +300,29 @@ def test_resume_reference_checkpoint_then_sample_golden():
     _, eps_raw = tr.sample(2, x0=a["x0"], noise=a["noises"])
     assert rel_mse(eps_raw.cpu(), a["eps_raw_weights"]) < TOL_LATENT
     assert rel_mse(eps_raw.cpu(), a["eps"]) > 30 * TOL_LATENT         # the swap matters (golden: 9.9e-3)
+
+
+def test_score_unet_variant_golden(tiny_cfg):
+    """(f)4: `unet: True` Score (up / mid / down blocks with skip concats, conv shortcut, adaLN1/adaLN2) vs the golden
+    captured from the reference; the sampler drives it through the generic loop."""
+    import copy
+    import ldt_amd
+    a, sds = load_golden("score_unet_tiny")
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.unet, cfg.score.num_blocks = True, int(a["num_blocks"])
+    score = ldt_amd.Score(cfg.score)
+    score.load_state_dict(sds["w"], strict=True)
+    score = score.cuda()
+    out = score(a["x"].cuda(), a["t"].cuda())
+    assert rel_mse(out.cpu(), a["out"]) < TOL_PARAMS
+    out_img = score(a["x"].cuda(), a["t"].cuda(), condition=(None, a["img_cond"].cuda()))
+    assert rel_mse(out_img.cpu(), a["out_img"]) < TOL_PARAMS
+    tr = ldt_amd.Trainer(cfg, score, ldt_amd.Compressor(cfg.compressor), "cuda:0")
+    from oracle import ldt_oracle as O
+    N = cfg.sde.sample_N
+    x0, noises = O.draw_noises(77, 2, cfg.score.z_scale, cfg.score.z_dim, N)
+    pts, eps = tr.sample(2, x0=x0, noise=torch.stack(noises))
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, tt: O.score_forward(sds["w"], cfg.score, x, tt))
+    ref = O.sample_discrete(sde, fn, x0, noises, N)
+    assert rel_mse(eps.cpu(), ref) < TOL_LATENT and torch.isfinite(pts).all()

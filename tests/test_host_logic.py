@@ -144,9 +144,10 @@ def test_unsupported_options_raise(tiny_cfg):
     with pytest.raises(ValueError):                # a raw condition dict without cfg.score.condition=True
         ldt_amd.Score(tiny_cfg.score).condition_embedding(None, {"pts": torch.zeros(1, 96, 3)})
     c = copy.deepcopy(tiny_cfg)
-    c.score.unet = True
-    with pytest.raises(NotImplementedError):
-        ldt_amd.Score(c.score)
+    c.score.unet = True                            # built: up/mid/down parameter tree with the reference's names
+    names = list(ldt_amd.Score(c.score).state_dict())
+    assert "Transformer_Down.0.shortcut.weight" in names and "Transformer_Mid.adaLN.1.weight" in names
+    assert not any(n.startswith("Transformer.") for n in names)
     c = copy.deepcopy(tiny_cfg)
     c.compressor.pos_embedding = "mlp"
     with pytest.raises(NotImplementedError):

@@ -228,3 +228,14 @@ def test_condition_net_point_branch():
     x = O.linear(sd, "c_net.pc_conv_in", a["pts"])
     _, tok, _, _ = O.local_grouper(sd, "c_net.group", a["pts"], x, int(a["patch_size"]), int(a["k"]), normalize="anchor")
     assert rel_mse(O.linear(sd, "c_net.pc_conv_out", tok), a["pts_condition"].transpose(1, 2)) > 1e-3
+
+
+def test_score_unet_variant(tiny_cfg):
+    """(f)4: `unet: True` Score (score.py:67-83,138-146) incl. the dim_in != dim_out down blocks (layers.py:216-218)."""
+    import copy
+    a, sds = load_golden("score_unet_tiny")
+    cfg = copy.deepcopy(tiny_cfg.score)
+    cfg.unet, cfg.num_blocks = True, int(a["num_blocks"])
+    assert any(k.startswith("Transformer_Down.0.adaLN2") for k in sds["w"])
+    assert rel_mse(O.score_forward(sds["w"], cfg, a["x"], a["t"]), a["out"]) < TOL
+    assert rel_mse(O.score_forward(sds["w"], cfg, a["x"], a["t"], condition=(None, a["img_cond"])), a["out_img"]) < TOL
