@@ -134,6 +134,19 @@ int ldt_reparam(const float* post, const float* noise, float* out, int64_t ldo, 
                 int64_t rows, int32_t z, float lo, float hi, void* stream);
 int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na, int32_t nb, float* dl, float* dr, void* stream);
 
+/* ---- generation-quality metrics of the validation loop (evaluation/evaluation_metrics.py:112-277) ----
+ * ldt_chamfer_pairwise: cd[s][r] = dl.mean(1) + dr.mean(1) of distChamfer(x[s], y[r]) for all S*R cloud pairs — the
+ *   matrix `_pairwise_CD_` (:165-199) / `_pairwise_EMD_CD_` (:112-162) build row by row.  x fp32 [S][n][3],
+ *   y fp32 [R][m][3], cd fp32 [S][R].
+ * ldt_emd_approx: transport cost of the approximate matching of
+ *   evaluation/pytorch_structural_losses/src/approxmatch.cu (approxmatchkernel :3-186 + matchcostkernel :188-224),
+ *   i.e. what `match_cost(xyz1, xyz2)` returns (emd_approx_cuda, evaluation_metrics.py:40-46, divides it by n).
+ *   pairwise = 0: out[b] for the pairs (x[b], y[b]), S == R;  pairwise = 1: out[s][r] for all S*R pairs.
+ *   n + m <= 7680 points (both clouds and the marginals stay in LDS). */
+int ldt_chamfer_pairwise(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, float* cd, void* stream);
+int ldt_emd_approx(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, int32_t pairwise,
+                   float* out, void* stream);
+
 /* ---- Score network forward: model/scorenet/score.py:117-151 (Transformer path, unet False) ------------- */
 typedef struct ldt_score_plan {
     int32_t hidden, heads, blocks, z_dim, z_pad, mlp_hidden, tokens, batch;

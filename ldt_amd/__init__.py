@@ -8,8 +8,9 @@ from .compressor import Compressor
 from .condition import ConditionNet
 from .config import airplane_config, dict2namespace, load_config
 from .diffusion import DiffusionVPSDE, make_diffusion
+from . import metrics
 from .score import Score
 from .trainer import EMAWeights, Trainer
 
 __all__ = ["Score", "Compressor", "ConditionNet", "DiffusionVPSDE", "make_diffusion", "Trainer", "EMAWeights", "dict2namespace",
-           "airplane_config", "load_config"]
+           "airplane_config", "load_config", "metrics"]

@@ -141,6 +141,16 @@ extern "C" int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na
     return ldt_chamfer_launch(a, b, B, na, nb, dl, dr, ST(stream));
 }
 
+extern "C" int ldt_chamfer_pairwise(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, float* cd, void* stream) {
+    LDT_REQUIRE(x && y && cd, LDT_EARG, "chamfer_pairwise: null pointer");
+    return ldt_chamfer_pairwise_launch(x, y, S, R, n, m, cd, ST(stream));
+}
+extern "C" int ldt_emd_approx(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, int32_t pairwise,
+                              float* out, void* stream) {
+    LDT_REQUIRE(x && y && out, LDT_EARG, "emd_approx: null pointer");
+    return ldt_emd_approx_launch(x, y, S, R, n, m, pairwise, out, ST(stream));
+}
+
 // ------------------------------------------------------------------------------ Score forward
 static int check_plan(const ldt_score_plan* p) {
     LDT_REQUIRE(p, LDT_EARG, "score: null plan");

@@ -76,4 +76,6 @@ int ldt_actnorm_launch(float* x, const float* shift, const float* log_scale, lon
 int ldt_reparam_launch(const float* post, const float* noise, float* out, long ldo, float* mu_out, float* lv_out,
                        long rows, int z, float lo, float hi, hipStream_t s);
 int ldt_chamfer_launch(const float* a, const float* b, int B, int na, int nb, float* dl, float* dr, hipStream_t s);
+int ldt_chamfer_pairwise_launch(const float* x, const float* y, int S, int R, int n, int m, float* cd, hipStream_t st);
+int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, int m, int pairwise, float* out, hipStream_t st);
 int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, hipStream_t s);

@@ -222,3 +222,26 @@ def chamfer(a, b):
     dr = torch.empty((B, na), dtype=torch.float32, device=a.device)
     check(lib().ldt_chamfer(_p(a), _p(b), B, na, nb, _p(dl), _p(dr), stream_ptr()), "ldt_chamfer")
     return dl, dr
+
+
+def chamfer_pairwise(x, y):
+    """x [S,n,3], y [R,m,3] fp32 -> cd [S,R]: dl.mean(1) + dr.mean(1) of distChamfer for every cloud pair."""
+    _need(x, torch.float32, "x"); _need(y, torch.float32, "y")
+    x, y = x.contiguous(), y.contiguous()
+    S, n, _ = x.shape
+    R, m, _ = y.shape
+    cd = torch.empty((S, R), dtype=torch.float32, device=x.device)
+    check(lib().ldt_chamfer_pairwise(_p(x), _p(y), S, R, n, m, _p(cd), stream_ptr()), "ldt_chamfer_pairwise")
+    return cd
+
+
+def emd_approx(x, y, pairwise=False):
+    """Approximate-matching transport cost (approxmatch + matchcost): x [S,n,3], y [R,m,3] fp32 ->
+    [S] (pairs (x[b], y[b])) or [S,R] (pairwise)."""
+    _need(x, torch.float32, "x"); _need(y, torch.float32, "y")
+    x, y = x.contiguous(), y.contiguous()
+    S, n, _ = x.shape
+    R, m, _ = y.shape
+    out = torch.empty((S, R) if pairwise else (S,), dtype=torch.float32, device=x.device)
+    check(lib().ldt_emd_approx(_p(x), _p(y), S, R, n, m, int(pairwise), _p(out), stream_ptr()), "ldt_emd_approx")
+    return out

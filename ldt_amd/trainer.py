@@ -120,8 +120,12 @@ class Trainer:
         return sample, eps
 
     @torch.no_grad()
-    def valsample(self, batches, batch_size=None):
-        """Timing loop of valsample (:167-206): returns (all samples, shapes/second) and prints "Sample rate"."""
+    def valsample(self, batches, batch_size=None, ref=None, save_npy=False):
+        """The reference's validation sampling loop (:167-226): `batches` calls of `sample(batch_size)`, the "Sample rate"
+        print (:206), optionally the `smp_ep<epoch>.npy` dump into cfg.log.save_path (:207-210) and — when reference
+        clouds `ref` (N, points, 3) are given in place of the test loader (datasets are out of scope) — the generation
+        metrics of `compute_all_metrics(smp, ref)` (:217-226) as {"val/gen/<key>": float}.
+        Returns (samples, shapes/second) or, with `ref`, (samples, shapes/second, metrics)."""
         batch_size = batch_size or self.cfg.data.test_batch_size
         out, use_time = [], 0.
         for _ in range(batches):
@@ -132,9 +136,21 @@ class Trainer:
             use_time += time.time() - T0
             out.append(smp)
         smp = torch.cat(out, 0)
+        if ref is not None:
+            smp = smp[:ref.shape[0]]                                                  # :203
         rate = smp.shape[0] / use_time
         print("Sample rate: %.8f " % rate)
-        return smp, rate
+        if save_npy:
+            import os
+            import numpy as np
+            np.save(os.path.join(self.cfg.log.save_path, "smp_ep%d" % self.epoch + ".npy"), smp.detach().cpu().numpy())
+        if ref is None:
+            return smp, rate
+        from .metrics import compute_all_metrics
+        gen_res = compute_all_metrics(smp, ref.to(smp), batch_size=64)
+        all_res = {("val/gen/%s" % k): (v if isinstance(v, float) else v.item()) for k, v in gen_res.items()}
+        print("Validation Sample (unit) Epoch:%d " % self.epoch, gen_res)
+        return smp, rate, all_res
 
     # ---- checkpoints: the reference's dict layout (:228-266) ------------------------------------------
     def resume(self, epoch=None, strict=False, load_optim=True, finetune=False, pretrain=None, **kwargs):

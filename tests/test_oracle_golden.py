@@ -239,3 +239,34 @@ def test_score_unet_variant(tiny_cfg):
     assert any(k.startswith("Transformer_Down.0.adaLN2") for k in sds["w"])
     assert rel_mse(O.score_forward(sds["w"], cfg, a["x"], a["t"]), a["out"]) < TOL
     assert rel_mse(O.score_forward(sds["w"], cfg, a["x"], a["t"], condition=(None, a["img_cond"])), a["out_img"]) < TOL
+
+
+def test_validation_metrics_cd():
+    """(f)4: pairwise CD, MMD/COV and the 1-NN test vs the reference's evaluation module on CPU."""
+    a, _ = load_golden("metrics_cd")
+    M_rs = O.pairwise_cd(a["ref"], a["smp"])
+    assert rel_mse(M_rs, a["M_rs"]) < 1e-10
+    mc = O.lgan_mmd_cov(a["M_rs"].t())
+    assert torch.allclose(mc["mmd"], a["lgan_mmd"]) and float(mc["cov"]) == float(a["lgan_cov"])
+    k1 = O.knn_two_sample(a["M_rr"], a["M_rs"], a["M_ss"], 1)
+    for nm in ("acc", "tp", "fp", "fn", "tn"):
+        assert float(k1[nm]) == float(a["knn1_" + nm]), nm
+    res = O.compute_cd_metrics(a["smp"], a["ref"])
+    assert torch.allclose(res["mmd-CD"], a["mmd_cd"]) and float(res["cov-CD"]) == float(a["cov_cd"])
+    assert float(res["1-NN-CD-acc"]) == float(a["one_nn_cd_acc"])
+    assert 0.0 < float(a["cov_cd"]) < 1.0 and 0.0 < float(a["one_nn_cd_acc"]) < 1.0       # a non-trivial fixture
+
+
+def test_emd_approxmatch_properties():
+    """EMD restatement (approxmatch.cu; parity unpinned — CUDA-only upstream): sanity anchors.  The matching transports
+    (almost) all mass, so cost/n is bounded below by ~the exact assignment's mean distance (the reference's CPU fallback
+    `emd_approx`, golden `emd_exact`) and stays within a modest factor of it; identical clouds cost ~0."""
+    a, _ = load_golden("metrics_cd")
+    x, y = a["smp"][:6], a["ref"][:6]
+    approx = O.emd_approxmatch_cost(x, y) / x.shape[1]
+    exact = a["emd_exact"]
+    assert (approx > 0.97 * exact).all() and (approx < 1.6 * exact).all(), (approx, exact)
+    same = O.emd_approxmatch_cost(x[:2], x[:2]) / x.shape[1]
+    assert (same < 0.05 * exact[:2]).all(), same
+    perm = torch.randperm(x.shape[1], generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(O.emd_approxmatch_cost(x[:2][:, perm], y[:2]), O.emd_approxmatch_cost(x[:2], y[:2]), rtol=1e-4)
