@@ -134,6 +134,16 @@ int ldt_reparam(const float* post, const float* noise, float* out, int64_t ldo, 
                 int64_t rows, int32_t z, float lo, float hi, void* stream);
 int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na, int32_t nb, float* dl, float* dr, void* stream);
 
+/* ---- fused MLP half of a narrow ResidualBlock (the Compressor's d = 128 blocks; model/layers.py:219,226 + :110-133) ----
+ * In place on x fp32 [M][ldx]:  x += gate * (W_dn . GELU(W_up . h + b_up) + b_dn),  h = LN(x) * ln_w + ln_b  (affine,
+ * no-condition blocks) or LN(x) * (1 + scale) + shift (AdaLN; shift/scale/gate are per-sample vectors, sample =
+ * row / rows_per_sample, consecutive samples mod_sample_stride floats apart).  C in {64, 128}; w_up bf16 [4C][C],
+ * w_dn bf16 [C][4C], both row-major and dense.  One pass over x instead of LayerNorm + two GEMMs. */
+int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                     const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
+                     int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
+                     const float* b_dn, void* stream);
+
 /* ---- generation-quality metrics of the validation loop (evaluation/evaluation_metrics.py:112-277) ----
  * ldt_chamfer_pairwise: cd[s][r] = dl.mean(1) + dr.mean(1) of distChamfer(x[s], y[r]) for all S*R cloud pairs — the
  *   matrix `_pairwise_CD_` (:165-199) / `_pairwise_EMD_CD_` (:112-162) build row by row.  x fp32 [S][n][3],

@@ -15,6 +15,11 @@ from ._lib import ACT_SILU, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32
 from .layers import conv_w
 
 
+# the fused LN+MLP kernel serves 64- and 128-channel blocks; LDT_FUSED_MLP=0 keeps the three-kernel path (A/B runs)
+import os
+FUSED_MLP = os.environ.get("LDT_FUSED_MLP", "1") != "0"
+
+
 def _bf(w):
     w = w.detach().float().contiguous()
     return ops.cast_pad_bf16(w, ops.pad64(w.shape[1]))
@@ -74,6 +79,14 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
         x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)
     ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
                   gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=Nq)
+    if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0:
+        # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
+        if c is not None:
+            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], shift=sh2, scale=sc2, gate=g2,
+                              mod_sample_stride=s2, rows_per_sample=Nq)
+        else:
+            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1])
+        return x
     if c is not None:
         h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=Nq)
     else:

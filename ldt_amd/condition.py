@@ -9,8 +9,8 @@ the pair the loop consumes: `(pts_condition (B, hidden, S), img_condition (B, p_
   * image branch (score.py:33-36): the first six children of torchvision's resnet18, global max pool, Linear
     128->p_dim.  torchvision is not in this image, so the trunk's parameter tree is laid out here under the names
     its state_dict has upstream (`resnet.0` conv1, `resnet.1` bn1, `resnet.4.{0,1}` layer1, `resnet.5.{0,1}` layer2
-    with `downsample.{0,1}` on its first block) and run with PyTorch-ROCm's conv2d ("resnet18 trunk
-    stays in PyTorch-ROCm"); PARITY UNPINNED against torchvision itself (tests compare with an independent fp32 restatement).
+    with `downsample.{0,1}` on its first block); the convolutions run as im2col + the fp32 HIP GEMM (BatchNorm folded,
+    deterministic); PARITY UNPINNED against torchvision itself (tests compare with an independent fp32 restatement).
 """
 import torch
 import torch.nn as nn
@@ -105,20 +105,30 @@ class ConditionNet(nn.Module):
         return out.view(B, self.patch_size, self.hidden_size).transpose(1, 2)
 
     def image_branch(self, img):
-        """img (B, 3, H, W) -> img_condition (B, p_dim): resnet18[:6] (eval-mode BatchNorm), global max pool, Linear."""
+        """img (B, 3, H, W) -> img_condition (B, p_dim): resnet18[:6] (eval-mode BatchNorm), global max pool, Linear.
+        Every convolution is im2col (`F.unfold`: a gather) + the fp32 HIP GEMM with the BatchNorm folded into its weights and
+        the ReLU into its epilogue — deterministic run to run, unlike the library convolutions."""
+        from ._lib import ACT_NONE, ACT_RELU
         r = self.resnet
-        h = img.to(self._device(), torch.float32)
+        h = img.to(self._device(), torch.float32).contiguous()
 
-        def bn(m, x):
-            return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, False, 0., m.eps)
+        def conv_bn(x, conv, bn, relu):
+            B, _, H, W = x.shape
+            k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            w = (conv.weight.detach().float().flatten(1) * s[:, None]).contiguous()
+            b = (bn.bias.detach().float() - bn.running_mean.float() * s).contiguous()
+            cols = F.unfold(x, k, padding=pd, stride=st).transpose(1, 2).reshape(B * Ho * Wo, -1).contiguous()
+            y = ops.sgemm(cols, w, b, act_out=ACT_RELU if relu else ACT_NONE)                   # [B*Ho*Wo, Cout]
+            return y.view(B, Ho * Wo, -1).transpose(1, 2).reshape(B, -1, Ho, Wo)
 
-        h = F.max_pool2d(F.relu(bn(r[1], F.conv2d(h, r[0].weight, None, 2, 3))), 3, 2, 1)
+        h = F.max_pool2d(conv_bn(h, r[0], r[1], True), 3, 2, 1)
         for layer in (r[4], r[5]):
             for blk in layer:
-                y = F.relu(bn(blk.bn1, F.conv2d(h, blk.conv1.weight, None, blk.stride, 1)))
-                y = bn(blk.bn2, F.conv2d(y, blk.conv2.weight, None, 1, 1))
+                y = conv_bn(conv_bn(h, blk.conv1, blk.bn1, True), blk.conv2, blk.bn2, False)
                 if blk.downsample is not None:
-                    h = bn(blk.downsample[1], F.conv2d(h, blk.downsample[0].weight, None, blk.stride, 0))
+                    h = conv_bn(h, blk.downsample[0], blk.downsample[1], False)
                 h = F.relu(y + h)
         h = F.adaptive_max_pool2d(h, 1).flatten(1).contiguous()
         return ops.sgemm(h, self.ln.weight.detach().float().contiguous(), self.ln.bias.detach().float().contiguous())

@@ -141,6 +141,14 @@ extern "C" int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na
     return ldt_chamfer_launch(a, b, B, na, nb, dl, dr, ST(stream));
 }
 
+extern "C" int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                                const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
+                                int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
+                                const float* b_dn, void* stream) {
+    LDT_REQUIRE(x && w_up && b_up && w_dn && b_dn, LDT_EARG, "ln_mlp: null pointer");
+    MlpArgs a{x, ldx, M, ln_w, ln_b, shift, scale, gate, mod_sample_stride, rows_per_sample, BF(w_up), b_up, BF(w_dn), b_dn};
+    return ldt_ln_mlp_launch(&a, C, ST(stream));
+}
 extern "C" int ldt_chamfer_pairwise(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, float* cd, void* stream) {
     LDT_REQUIRE(x && y && cd, LDT_EARG, "chamfer_pairwise: null pointer");
     return ldt_chamfer_pairwise_launch(x, y, S, R, n, m, cd, ST(stream));

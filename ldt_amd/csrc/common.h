@@ -57,4 +57,21 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float phi = 0.5f * erfc_z;                                                    // Phi(-|x|)
     return x * (x >= 0.f ? 1.0f - phi : phi);
 }
+// two-lane form of gelu_erf_fast for VALU-bound epilogues: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 den = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f32x2 e = z * z * (-1.4426950408889634f);
+    const f32x2 ex = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    // x Phi(x) = x/2 + |x| (1/2 - Phi(-|x|)),  Phi(-|x|) = erfc(z)/2 = p t ex / 2 : no compare/select
+    const f32x2 r = (p * t) * ex * (-0.5f) + 0.5f;
+    return x * 0.5f + ax * r;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

@@ -1,0 +1,282 @@
+// Fused MLP half of a Set-Transformer ResidualBlock for narrow channel counts (the Compressor: d = 128, 4d hidden;
+// reference model/layers.py:219 / :226 with MLP :110-133 and the LayerNorm wrapper tools/utils.py:127-133):
+//
+//     x  <-  x + gate * ( W_dn · GELU( W_up · h + b_up ) + b_dn ),      h = LN(x)[*w + b]  or  LN(x)*(1+scale)+shift
+//
+// in ONE pass over x.  Unfused this is LayerNorm + two GEMMs: x is read twice and written once in fp32, h written and
+// read in bf16, and the 4d-wide hidden activation written and read in bf16 — 22 B/channel·row of HBM traffic against
+// the 8 B/channel·row (x in, x out) this kernel moves.  At d = 128 the GEMMs have K = 128 / 512: far below the MFMA
+// ridge, so the unfused path is HBM-bound and the fused one becomes MFMA/LDS-bound.
+//
+// Workgroup = 4 waves x 32 rows = 128 rows; two workgroups share a CU (80 KB LDS each, <= 256 VGPRs).  Per wave:
+//   1. LN: the wave's 32 rows are read in the MFMA accumulator layout (16 B per lane), statistics in-lane + two
+//      cross-lane adds, h -> bf16 -> wave-private rows of an LDS image (XOR-swizzled 16-B chunks) -> read back ONCE as
+//      the MFMA operand fragments of the wave's rows, which then stay in 8*C/32 VGPRs; the image's LDS becomes the
+//      second weight buffer.  Without a gate the x values just read initialise the output accumulators (x + b_dn).
+//   2. for each chunk of 64 hidden units (weights W_up[64 x C], W_dn[C x 64] staged L2 -> LDS by LDS-DMA, shared by
+//      the 4 waves, double-buffered: chunk c+1 is in flight during the whole of chunk c, one barrier per chunk):
+//        U^T[64 x 32]  = W_up_c · h^T          (mfma 16x16x32 bf16; operands swapped so a lane holds 4 consecutive
+//        U = GELU(U + b_up) -> bf16 -> LDS       hidden units of one row -> one 8-B LDS store)
+//        O^T[C x 32] += W_dn_c · U^T           (a lane holds 4 consecutive output channels of one row)
+//   3. epilogue from registers, 16 B per lane: the accumulators ARE the new x (no gate), or x + gate * (O + b_dn).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int C> struct MlpCfg {
+    static constexpr int HID = 4 * C;
+    static constexpr int HCH = 64;                         // hidden units per chunk
+    static constexpr int NCH = HID / HCH;
+    static constexpr int ROWB = C * 2;                     // bytes of one bf16 row of width C
+    static constexpr int CB = C / 8;                       // 16-B chunks per such row
+    static constexpr int H_BYTES = 128 * ROWB;             // h image: 128 rows x C
+    static constexpr int U_BYTES = 128 * HCH * 2;          // GELU output chunk: 128 rows x 64
+    static constexpr int WUP_BYTES = HCH * ROWB;           // W_up chunk: 64 rows x C
+    static constexpr int WDN_BYTES = C * HCH * 2;          // W_dn chunk: C rows x 64
+    static constexpr int LDS = H_BYTES + U_BYTES + WUP_BYTES + WDN_BYTES;   // h image (later weight set 1) | U | weight set 0
+};
+
+// bank-conflict swizzle of the 16-B chunk index inside a row of `CB` chunks (both-sides rule: the same function on
+// the LDS-DMA source address, on plain LDS stores and on every ds_read)
+template <int CB> __device__ __forceinline__ int swz(int row) { return CB == 16 ? (row & 15) : ((row >> 1) & 7); }
+
+template <int C>
+__device__ __forceinline__ void stage_wup(const bf16_t* __restrict__ w_up, int hid0, char* lds, int wave, int lane) {
+    constexpr int CB = MlpCfg<C>::CB, RPP = 64 / CB, PIECES = MlpCfg<C>::WUP_BYTES / 1024;    // rows per 1-KiB piece
+#pragma unroll
+    for (int p = wave; p < PIECES; p += 4) {
+        const int row = p * RPP + lane / CB, phys = lane % CB;
+        const bf16_t* src = w_up + (long)(hid0 + row) * C + ((phys ^ swz<CB>(row)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+    }
+}
+template <int C>
+__device__ __forceinline__ void stage_wdn(const bf16_t* __restrict__ w_dn, int hid0, char* lds, int wave, int lane) {
+    constexpr int PIECES = MlpCfg<C>::WDN_BYTES / 1024;                                       // 8 rows of 128 B per piece
+#pragma unroll
+    for (int p = wave; p < PIECES; p += 4) {
+        const int row = p * 8 + (lane >> 3), phys = lane & 7;
+        const bf16_t* src = w_dn + (long)row * MlpCfg<C>::HID + hid0 + ((phys ^ swz<8>(row)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
+    }
+}
+
+template <int C, bool GATED>
+__global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
+    using K = MlpCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) char mlp_smem[];
+    // [ weight set 1 = h image during the LayerNorm | U | weight set 0 ]
+    char* Hs = mlp_smem;
+    char* Us = Hs + K::H_BYTES;
+    char* W0 = Us + K::U_BYTES;
+    static_assert(K::H_BYTES >= K::WUP_BYTES + K::WDN_BYTES, "the h image must be able to hold one weight chunk");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * 128 + wave * 32;              // this wave's 32 rows
+    const int lrow = lane & 15, lq = lane >> 4;
+
+    stage_wup<C>(a.w_up, 0, W0, wave, lane);                           // chunk 0 weights fly under the LayerNorm
+    stage_wdn<C>(a.w_dn, 0, W0 + K::WUP_BYTES, wave, lane);
+
+    // ---- 1. LayerNorm (+ affine | modulate) of the wave's rows -> bf16 image --------------------------------------
+    // x is read in the accumulator layout (lane: row rt*16 + lrow, channels n*16 + lq*4 .. +3) so that, when there is no
+    // gate, it simply becomes the initial value of the output accumulators (x + b_dn) and is never read again.
+    f32x4 oacc[C / 16][2];
+    {
+        bf16x4 hpk[C / 16][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            long grow = row0 + rt * 16 + lrow;
+            grow = grow < a.M ? grow : a.M - 1;                        // tail rows: clamp, never stored
+            const float* xr = a.x + grow * a.ldx + lq * 4;
+            f32x4 v[C / 16];
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) v[n] = *reinterpret_cast<const f32x4*>(xr + n * 16);
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) s += (v[n][0] + v[n][1]) + (v[n][2] + v[n][3]);
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            const float mean = s / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[n][j] - mean; q += d * d; }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q / (float)C + 1e-6f);
+            const long moff = a.shift ? (grow / a.rows_per_sample) * a.mod_sample_stride : 0;
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) {
+                const int col = n * 16 + lq * 4;
+                f32x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = (v[n][j] - mean) * rstd;
+                if (a.ln_w) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.ln_w + col), b = *reinterpret_cast<const f32x4*>(a.ln_b + col);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = h[j] * w[j] + b[j];
+                }
+                if (a.shift) {
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + moff + col), sc = *reinterpret_cast<const f32x4*>(a.scale + moff + col);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = h[j] * (1.f + sc[j]) + sh[j];
+                }
+                hpk[n][rt] = (bf16x4){(bf16_t)h[0], (bf16_t)h[1], (bf16_t)h[2], (bf16_t)h[3]};
+                if (GATED) {
+                    oacc[n][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + col);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) oacc[n][rt][j] = v[n][j] + b4[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) {
+                const int hr = wave * 32 + rt * 16 + lrow;
+                *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) = hpk[n][rt];
+            }
+    }
+    // the wave's rows as MFMA operand fragments, for the whole kernel (rows are wave-private: no barrier needed to read)
+    bf16x8 hf[C / 32][2];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int hr = wave * 32 + rt * 16 + lrow;
+            hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
+        }
+
+    // ---- 2. hidden chunks ------------------------------------------------------------------------------------------
+#ifdef MLP_DBG_NCH
+    for (int ch = 0; ch < MLP_DBG_NCH; ++ch) {
+#else
+    for (int ch = 0; ch < K::NCH; ++ch) {
+#endif
+        // chunk ch's weights (issued one chunk ago) have landed for this wave; after the barrier: for every wave, and every
+        // wave is past chunk ch-1 (and, at ch = 0, has its h fragments in registers), so the other set may be refilled
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* Wu = (ch & 1) ? Hs : W0;
+        char* Wd = Wu + K::WUP_BYTES;
+        if (ch + 1 < K::NCH) {
+            char* Wn = (ch & 1) ? W0 : Hs;
+            stage_wup<C>(a.w_up, (ch + 1) * K::HCH, Wn, wave, lane);
+            stage_wdn<C>(a.w_dn, (ch + 1) * K::HCH, Wn + K::WUP_BYTES, wave, lane);
+        }
+        f32x4 uacc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+            const int c = ks * 4 + lq;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int wr = t * 16 + lrow;
+                wf[t] = *reinterpret_cast<const bf16x8*>(Wu + wr * K::ROWB + ((c ^ swz<K::CB>(wr)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
+        }
+        // bias + exact-erf GELU -> bf16 -> wave-private rows of U   (lane: hidden t*16 + lq*4 + i, row rt*16 + lrow)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_up + ch * K::HCH + t * 16 + lq * 4);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 v = uacc[t][rt];
+#ifdef MLP_DBG_NOGELU
+                const f32x2 g0 = {v[0] + b4[0], v[1] + b4[1]}, g1 = {v[2] + b4[2], v[3] + b4[3]};
+#else
+                const f32x2 g0 = gelu_erf_fast2((f32x2){v[0] + b4[0], v[1] + b4[1]});
+                const f32x2 g1 = gelu_erf_fast2((f32x2){v[2] + b4[2], v[3] + b4[3]});
+#endif
+                const bf16x4 pk = {(bf16_t)g0[0], (bf16_t)g0[1], (bf16_t)g1[0], (bf16_t)g1[1]};
+                const int ur = wave * 32 + rt * 16 + lrow;
+                *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // U rows are wave-private: ordering inside the wave suffices
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + lq;
+            bf16x8 uf[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int ur = wave * 32 + rt * 16 + lrow;
+                uf[rt] = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((c ^ swz<8>(ur)) << 4));
+            }
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) {
+                const int wr = n * 16 + lrow;
+                const bf16x8 df = *reinterpret_cast<const bf16x8*>(Wd + wr * 128 + ((c ^ swz<8>(wr)) << 4));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) oacc[n][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, uf[rt], oacc[n][rt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- 3. store: lane holds channels n*16 + lq*4 .. +3 of row rt*16 + lrow ---------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const long grow = row0 + rt * 16 + lrow;
+        if (grow >= a.M) continue;
+        float* xr = a.x + grow * a.ldx;
+        if (GATED) {                                                   // x + gate * (O + b_dn): x is read again (AdaLN blocks)
+            const float* g = a.gate + (grow / a.rows_per_sample) * a.mod_sample_stride;
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) {
+                const int col = n * 16 + lq * 4;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + col), g4 = *reinterpret_cast<const f32x4*>(g + col);
+                f32x4 xo = *reinterpret_cast<const f32x4*>(xr + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xo[j] = xo[j] + g4[j] * (oacc[n][rt][j] + b4[j]);
+                *reinterpret_cast<f32x4*>(xr + col) = xo;
+            }
+        } else {                                                       // the accumulators started from x + b_dn
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) *reinterpret_cast<f32x4*>(xr + n * 16 + lq * 4) = oacc[n][rt];
+        }
+    }
+}
+
+template <int C, bool GATED>
+int launch_mlp(const MlpArgs* a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_resid_kernel<C, GATED>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C>::LDS);
+        if (e != hipSuccess) { ldt_set_error("ln_mlp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const long blocks = (a->M + 127) / 128;
+    hipLaunchKernelGGL((ln_mlp_resid_kernel<C, GATED>), dim3((unsigned)blocks), dim3(256), MlpCfg<C>::LDS, st, *a);
+    return ldt_check_launch("ln_mlp_resid");
+}
+
+}  // namespace
+
+int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st) {
+    LDT_REQUIRE(a->M > 0 && a->M < (1L << 31) * 128, LDT_ESHAPE, "ln_mlp: bad row count %ld", a->M);
+    LDT_REQUIRE(C == 64 || C == 128, LDT_ESHAPE, "ln_mlp: the fused kernel is built for 64 or 128 channels (got %d)", C);
+    LDT_REQUIRE(a->ldx >= C && a->ldx % 4 == 0 && ldt_aligned16(a->x), LDT_EALIGN, "ln_mlp: x rows must be 16-byte aligned");
+    LDT_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), LDT_EARG, "ln_mlp: affine weight and bias go together");
+    LDT_REQUIRE((a->shift == nullptr) == (a->scale == nullptr), LDT_EARG, "ln_mlp: shift and scale go together");
+    LDT_REQUIRE((!a->shift && !a->gate) || (a->rows_per_sample > 0 && a->mod_sample_stride % 4 == 0), LDT_EARG,
+                "ln_mlp: modulation / gate need rows_per_sample > 0 and a 16-byte aligned per-sample stride");
+    LDT_REQUIRE(ldt_aligned16(a->w_up) && ldt_aligned16(a->w_dn) && ldt_aligned16(a->b_up) && ldt_aligned16(a->b_dn) &&
+                (!a->ln_w || (ldt_aligned16(a->ln_w) && ldt_aligned16(a->ln_b))) &&
+                (!a->shift || (ldt_aligned16(a->shift) && ldt_aligned16(a->scale))) && (!a->gate || ldt_aligned16(a->gate)),
+                LDT_EALIGN, "ln_mlp: operands must be 16-byte aligned");
+    if (a->gate) return C == 128 ? launch_mlp<128, true>(a, st) : launch_mlp<64, true>(a, st);
+    return C == 128 ? launch_mlp<128, false>(a, st) : launch_mlp<64, false>(a, st);
+}

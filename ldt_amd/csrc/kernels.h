@@ -76,6 +76,17 @@ int ldt_actnorm_launch(float* x, const float* shift, const float* log_scale, lon
 int ldt_reparam_launch(const float* post, const float* noise, float* out, long ldo, float* mu_out, float* lv_out,
                        long rows, int z, float lo, float hi, hipStream_t s);
 int ldt_chamfer_launch(const float* a, const float* b, int B, int na, int nb, float* dl, float* dr, hipStream_t s);
+// fused LayerNorm + MLP + gated residual for narrow blocks (fused_mlp.hip)
+struct MlpArgs {
+    float* x; long ldx; long M;
+    const float* ln_w; const float* ln_b;              // affine LayerNorm (no-condition blocks) or null
+    const float* shift; const float* scale;            // AdaLN modulation (per sample) or null
+    const float* gate;                                 // per-sample gate or null (= 1)
+    long mod_sample_stride; int rows_per_sample;
+    const bf16_t* w_up; const float* b_up;             // [4C][C], [4C]
+    const bf16_t* w_dn; const float* b_dn;             // [C][4C], [C]
+};
+int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st);
 int ldt_chamfer_pairwise_launch(const float* x, const float* y, int S, int R, int n, int m, float* cd, hipStream_t st);
 int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, int m, int pairwise, float* out, hipStream_t st);
 int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, hipStream_t s);

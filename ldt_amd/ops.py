@@ -245,3 +245,15 @@ def emd_approx(x, y, pairwise=False):
     out = torch.empty((S, R) if pairwise else (S,), dtype=torch.float32, device=x.device)
     check(lib().ldt_emd_approx(_p(x), _p(y), S, R, n, m, int(pairwise), _p(out), stream_ptr()), "ldt_emd_approx")
     return out
+
+
+def ln_mlp_resid_(x, w_up, b_up, w_dn, b_dn, ln_w=None, ln_b=None, shift=None, scale=None, gate=None,
+                  mod_sample_stride=0, rows_per_sample=0):
+    """In place: x += gate * MLP(LN(x)[affine | modulated]) for C in {64, 128} channels (one fused kernel)."""
+    _need(x, torch.float32, "x"); _rowmajor(x, "x")
+    M, Cc = x.shape
+    if tuple(w_up.shape) != (4 * Cc, Cc) or tuple(w_dn.shape) != (Cc, 4 * Cc) or not (w_up.is_contiguous() and w_dn.is_contiguous()):
+        raise ValueError("ln_mlp_resid_: weights must be dense bf16 [4C][C] and [C][4C]")
+    check(lib().ldt_ln_mlp_resid(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
+                                 rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), stream_ptr()), "ldt_ln_mlp_resid")
+    return x
