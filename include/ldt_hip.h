@@ -75,6 +75,16 @@ int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy
 int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride,
                       const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride,
                       uint16_t* O, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream);
+/* Attention + output projection + gated residual in one kernel, for narrow blocks (the Compressor: Dh = 32,
+ * C = H*Dh in {64, 128}; model/layers.py:183-200 then :218 / :225):
+ *     X[b] += gate[b] * (Wo . O'[b] + bo),   O' = softmax(Q K^T / sqrt(Dh)) V written as [H][Nq][Dh] and re-read as
+ * (Nq, C) rows without permuting the heads back (quirk Q1) — so the rows a workgroup produces for head h and query
+ * block q0 are rows h*Nq/H + q0/H ... of X.  Needs Nq % H == 0.  X fp32 [B*Nq][ldx] updated in place (X must not alias
+ * Q/K/V); Wo bf16 [C][C] dense; gate fp32 per-sample vectors (nullable = 1). */
+int ldt_attention_oproj_resid(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride, const uint16_t* K, int64_t ldk,
+                              const uint16_t* V, int64_t ldv, int64_t kv_batch_stride, int32_t B, int32_t H,
+                              int32_t Nq, int32_t Nk, int32_t head_dim, const uint16_t* Wo, const float* bo, float* X,
+                              int64_t ldx, const float* gate, int64_t gate_sample_stride, void* stream);
 
 /* ---- fp32 linear for the small precision-critical layers ---------------------------------------------
  * C[M,N] = act_out( act_in(A[M,K]) · Bw[N,K]^T + bias ), fp32 FMA accumulate; out fp32 or bf16.

@@ -48,6 +48,7 @@ SIGNATURES = {
                       _i32, _i32, _i32, _vp],
     "ldt_layernorm_modulate": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
     "ldt_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ldt_attention_oproj_resid": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     "ldt_sgemm": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ldt_sinusoid": [_vp, _vp, _vp, _i32, _i32, _vp],
     "ldt_sampler_step": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _u64, _i32, _i32, _vp],

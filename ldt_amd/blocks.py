@@ -18,6 +18,7 @@ from .layers import conv_w
 # the fused LN+MLP kernel serves 64- and 128-channel blocks; LDT_FUSED_MLP=0 keeps the three-kernel path (A/B runs)
 import os
 FUSED_MLP = os.environ.get("LDT_FUSED_MLP", "1") != "0"
+FUSED_ATTN = os.environ.get("LDT_FUSED_ATTN", "1") != "0"
 
 
 def _bf(w):
@@ -73,12 +74,18 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
     if y_bf16 is None:
         y_bf16, Nk = h, Nq
     kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                        # [B*Nk, 2Co]: K | V  (layers.py:189)
-    a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)         # [B,H,Nq,Dh] == (B*Nq, Co) raw view
     if C != Co:                                                                     # shortcut(x): Conv1d dim_in -> dim_out
         from ._lib import EPI_F32
         x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)
-    ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
-                  gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=Nq)
+    if FUSED_ATTN and Co // H == 32 and H in (2, 4) and Nq % H == 0 and P["wo"].shape == (Co, Co):
+        # attention + out-projection + gated residual in ONE kernel (csrc/attention.hip, OPROJ): the [B,H,Nq,Dh]
+        # result never goes to HBM — the Compressor's d = 128 blocks
+        ops.attention_oproj_resid_(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, 32, P["wo"], P["bo"], x, gate=g1,
+                                   gate_sample_stride=s2 if g1 is not None else 0)
+    else:
+        a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)     # [B,H,Nq,Dh] == (B*Nq, Co) raw view
+        ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
+                      gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=Nq)
     if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0:
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
         if c is not None:

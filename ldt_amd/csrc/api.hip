@@ -71,8 +71,18 @@ extern "C" int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch
                                  int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream) {
     LDT_REQUIRE(Q && K && V && O, LDT_EARG, "attention: null pointer");
     AttnArgs a{BF(Q), ldq, q_batch_stride, BF(K), ldk, kv_batch_stride, BF(V), ldv, BFM(O), B, H, Nq, Nk,
-               1.4426950408889634f / sqrtf((float)head_dim)};
+               1.4426950408889634f / sqrtf((float)head_dim), nullptr, nullptr, nullptr, 0, nullptr, 0};
     return ldt_attn_launch(&a, head_dim, ST(stream));
+}
+extern "C" int ldt_attention_oproj_resid(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride, const uint16_t* K,
+                                         int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride,
+                                         int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim,
+                                         const uint16_t* Wo, const float* bo, float* X, int64_t ldx, const float* gate,
+                                         int64_t gate_sample_stride, void* stream) {
+    LDT_REQUIRE(Q && K && V && Wo && bo && X, LDT_EARG, "attention_oproj: null pointer");
+    AttnArgs a{BF(Q), ldq, q_batch_stride, BF(K), ldk, kv_batch_stride, BF(V), ldv, nullptr, B, H, Nq, Nk,
+               1.4426950408889634f / sqrtf((float)head_dim), BF(Wo), bo, X, ldx, gate, gate_sample_stride};
+    return ldt_attn_oproj_launch(&a, head_dim, ST(stream));
 }
 
 extern "C" int ldt_sgemm(const float* A, int64_t lda, const float* Bw, int64_t ldb, const float* bias, void* C,

@@ -93,7 +93,7 @@ __device__ __forceinline__ void attn_tile_softmax_pv(f32x16 (&sacc)[2], f32x16 (
         }
 }
 
-template <int DH>
+template <int DH, bool OPROJ = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                      // keys per LDS tile
     constexpr int ROWB = DH * 2;                // K / V row bytes
@@ -207,6 +207,72 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     //      and store whole rows, 16 B per lane: the row-per-lane fragment layout would touch 32 lines per store ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if (OPROJ) {
+        // ---- fused output projection + gated residual (narrow blocks).  The workgroup's 128 x DH outputs are one
+        //      contiguous piece of the [B][H][Nq][Dh] buffer = R = 128/H whole rows of the (B*Nq, C) matrix the reference
+        //      reinterprets it as (quirk Q1): stage them in LDS as those rows (B operand), Wo fragments straight from
+        //      L2 (A operand; every workgroup reads the same 2*C*C bytes), each wave takes C/4 output channels. ----
+        const int H = a.H, C = H * DH, R = 128 / H;
+        const int rowb = C * 2;
+        auto swzO = [&](int row) { return C == 128 ? (row & 15) : ((row >> 1) & 7); };
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                        // DH == 32: one 32-wide d tile
+            const int flat = (wave * 32 + r) * DH + 8 * g + 4 * hh;
+            const int orow = flat / C, ocol = flat % C;
+            const bf16x4 pk = {(bf16_t)(oacc[0][4 * g + 0] * inv), (bf16_t)(oacc[0][4 * g + 1] * inv),
+                               (bf16_t)(oacc[0][4 * g + 2] * inv), (bf16_t)(oacc[0][4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(smem + orow * rowb + (((ocol >> 3) ^ swzO(orow)) << 4) + (ocol & 7) * 2) = pk;
+        }
+        __syncthreads();
+        const int lrow = lane & 15, lq = lane >> 4;
+        const int NT = C / 64, RT = R / 16, n0 = wave * (C / 4);         // (NT, RT) = (2, 2) at C = 128, (1, 4) at C = 64
+        f32x4 pacc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < C / 32; ++ks) {
+            bf16x8 of[4], wf[2];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+                if (rt < RT) {
+                    const int orow = rt * 16 + lrow;
+                    of[rt] = *reinterpret_cast<const bf16x8*>(smem + orow * rowb + (((ks * 4 + lq) ^ swzO(orow)) << 4));
+                }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                if (nt < NT) wf[nt] = *reinterpret_cast<const bf16x8*>(a.Wo + (long)(n0 + nt * 16 + lrow) * C + ks * 32 + lq * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    if (nt < NT && rt < RT) pacc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], of[rt], pacc[nt][rt], 0, 0, 0);
+        }
+        const int qb0 = qblk * 128;
+        const int valid_rows = (min(128, a.Nq - qb0)) / H;               // Nq % H == 0 (checked by the launcher)
+        const long xrow0 = (long)b * a.Nq + ((long)head * a.Nq + qb0) / H;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (nt >= NT || rt >= RT) continue;
+                const int orow = rt * 16 + lrow, ch = n0 + nt * 16 + lq * 4;
+                if (orow >= valid_rows) continue;
+                float* xp = a.X + (xrow0 + orow) * a.ldx + ch;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + ch);
+                f32x4 xo = *reinterpret_cast<const f32x4*>(xp);
+                if (a.gate) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.gate + (long)b * a.gate_sample_stride + ch);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xo[j] += g4[j] * (pacc[nt][rt][j] + b4[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xo[j] += pacc[nt][rt][j] + b4[j];
+                }
+                *reinterpret_cast<f32x4*>(xp) = xo;
+            }
+        return;
+    }
     constexpr int ORS = ROWB + 16;                           // staged row stride (pad: conflict-free 8-B column writes)
     char* ost = smem + wave * (32 * ORS);                    // 4 waves x 32 rows x (ROWB+16) <= 4*TILE
 #pragma unroll
@@ -358,6 +424,21 @@ static int launch_resident(const AttnArgs* a, hipStream_t s) {
     }
     hipLaunchKernelGGL(attn_fwd_resident_kernel<DH>, dim3((unsigned)(a->B * a->H)), dim3(256), lds, s, *a, ntl);
     return ldt_check_launch("attn_fwd_resident");
+}
+
+int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s) {
+    LDT_REQUIRE(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, LDT_ESHAPE, "attention_oproj: empty problem");
+    LDT_REQUIRE(dh == 32 && (a->H == 2 || a->H == 4), LDT_ESHAPE,
+                "attention_oproj: the fused kernel is built for head dim 32 with 2 or 4 heads (C = 64 / 128), got Dh=%d H=%d", dh, a->H);
+    LDT_REQUIRE(a->Nq % a->H == 0, LDT_ESHAPE, "attention_oproj: Nq=%d must be a multiple of H=%d (rows of the reinterpreted output)", a->Nq, a->H);
+    LDT_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->q_batch_stride % 8 == 0 && a->kv_batch_stride % 8 == 0 &&
+                ldt_aligned16(a->Q) && ldt_aligned16(a->K) && ldt_aligned16(a->V) && ldt_aligned16(a->Wo) && ldt_aligned16(a->bo) &&
+                ldt_aligned16(a->X) && a->ldx % 4 == 0 && a->ldx >= a->H * dh && (!a->gate || (ldt_aligned16(a->gate) && a->gate_sample_stride % 4 == 0)),
+                LDT_EALIGN, "attention_oproj: operands must be 16-byte aligned");
+    const long nqb = (a->Nq + 127) / 128, groups = ((long)a->B * a->H + 7) / 8;
+    LDT_REQUIRE(groups * 8 * nqb < (1L << 31), LDT_ESHAPE, "attention_oproj: grid too large");
+    hipLaunchKernelGGL((attn_fwd_kernel<32, true>), dim3((unsigned)(groups * 8 * nqb)), dim3(256), 0, s, *a);
+    return ldt_check_launch("attn_oproj");
 }
 
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s) {

@@ -38,6 +38,9 @@ struct AttnArgs {
     bf16_t* O;                                          // [B][H][Nq][Dh]
     int B, H, Nq, Nk;
     float scale_log2e;                                  // Dh^-0.5 * log2(e)
+    // fused output projection (narrow blocks, Dh = 32, C = H*Dh in {64,128}):  X += gate * (Wo . O' + bo), O' = the
+    // [B][H][Nq][Dh] result re-read as (B*Nq, C) rows (quirk Q1); all null/0 for the plain kernel
+    const bf16_t* Wo; const float* bo; float* X; long ldx; const float* gate; long gate_sample_stride;
 };
 
 struct StepArgs {
@@ -58,6 +61,7 @@ struct SgemmArgs {
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);
+int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s);
 int ldt_cast_pad_launch(const float* src, long lds, bf16_t* dst, long ldd, long rows, int cols, int cols_pad, hipStream_t s);
 int ldt_sampler_step_launch(const StepArgs* a, hipStream_t s);
 int ldt_advance_step_launch(int* step_ptr, hipStream_t s);

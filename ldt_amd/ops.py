@@ -257,3 +257,18 @@ def ln_mlp_resid_(x, w_up, b_up, w_dn, b_dn, ln_w=None, ln_b=None, shift=None, s
     check(lib().ldt_ln_mlp_resid(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
                                  rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), stream_ptr()), "ldt_ln_mlp_resid")
     return x
+
+
+def attention_oproj_resid_(q, k, v, B, H, Nq, Nk, head_dim, wo, bo, x, gate=None, gate_sample_stride=0):
+    """In place: x[B*Nq, C] += gate * (Wo . Attn(q, k, v)' + bo) with the reference's raw head merge (quirk Q1), one kernel
+    (Dh = 32, H in {2, 4}).  q [B*Nq, >=C], k/v [B*Nk, ...] bf16 row views; wo bf16 [C][C] dense."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (wo, "wo")):
+        _need(t, torch.bfloat16, nm); _rowmajor(t, nm)
+    _need(x, torch.float32, "x"); _rowmajor(x, "x")
+    Cc = H * head_dim
+    if tuple(wo.shape) != (Cc, Cc) or not wo.is_contiguous() or x.shape != (B * Nq, Cc):
+        raise ValueError("attention_oproj_resid_: wo must be dense [C][C] and x [B*Nq, C]")
+    check(lib().ldt_attention_oproj_resid(_p(q), q.stride(0), q.stride(0) * Nq, _p(k), k.stride(0), _p(v), v.stride(0),
+                                          k.stride(0) * Nk, B, H, Nq, Nk, head_dim, _p(wo), _p(bo), _p(x), x.stride(0),
+                                          _p(gate), gate_sample_stride, stream_ptr()), "ldt_attention_oproj_resid")
+    return x
