@@ -154,6 +154,13 @@ int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* l
                      int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
                      const float* b_dn, void* stream);
 
+/* LayerNorm + linear for the same narrow blocks: out bf16 [M][ldo] = LN(x)[affine | modulated] . W^T + bias, W bf16 [N][C]
+ * dense, N % 64 == 0, C in {64, 128} — fc_q (and fc_kv when the block attends to its own normalised input,
+ * model/layers.py:184-189) fed straight from the LayerNorm without writing the normalised activations. */
+int ldt_ln_linear(const float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                  const float* shift, const float* scale, int64_t mod_sample_stride, int32_t rows_per_sample,
+                  const uint16_t* w, const float* bias, int32_t N, uint16_t* out, int64_t ldo, void* stream);
+
 /* ---- generation-quality metrics of the validation loop (evaluation/evaluation_metrics.py:112-277) ----
  * ldt_chamfer_pairwise: cd[s][r] = dl.mean(1) + dr.mean(1) of distChamfer(x[s], y[r]) for all S*R cloud pairs — the
  *   matrix `_pairwise_CD_` (:165-199) / `_pairwise_EMD_CD_` (:112-162) build row by row.  x fp32 [S][n][3],

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ldt_reparam": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, C.c_float, C.c_float, _vp],
     "ldt_chamfer": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ldt_ln_mlp_resid": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "ldt_ln_linear": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     "ldt_chamfer_pairwise": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_emd_approx": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_score_forward": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp],

@@ -40,6 +40,9 @@ def pack_block(blk):
         "n1": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm1.affine),
         "n2": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm2.affine),
     }
+    if C == Co and C in (64, 128) and blk.dim_kv == C:              # fc_q | fc_kv as one operand for the fused LN + linear kernel
+        P["wqkv"] = torch.cat([P["wq"], P["wkv"]], 0).contiguous()
+        P["bqkv"] = torch.cat([P["bq"], P["bkv"]], 0).contiguous()
     if blk.dim_c is not None and C == Co:
         lin = blk.adaLN[1]
         P["wada"], P["bada"] = lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous()
@@ -55,25 +58,43 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
     for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
     c: fp32 [B, dim_c] condition (AdaLN) or None (affine LayerNorm block)."""
     C, Co, H = P["C"], P["Co"], P["H"]
+    ln_kw = {}
     if c is not None and C == Co:
         mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                  # [B, 6C]  layers.py:214
         sh1, sc1, g1, sh2, sc2, g2 = (mod[:, i * C:(i + 1) * C] for i in range(6))
         s1 = s2 = 6 * C
-        h = ops.layernorm_modulate(x, shift=sh1, scale=sc1, mod_sample_stride=s1, rows_per_sample=Nq)
+        ln_kw = dict(shift=sh1, scale=sc1, mod_sample_stride=s1, rows_per_sample=Nq)
     elif c is not None:                                                             # layers.py:216-217
         m1 = ops.sgemm(c, P["wada1"], P["bada1"], act_in=ACT_SILU)                 # [B, 2C]   shift_msa | scale_msa
         mod = ops.sgemm(c, P["wada2"], P["bada2"], act_in=ACT_SILU)                # [B, 4Co]  gate_msa | shift_mlp | scale_mlp | gate_mlp
         g1, sh2, sc2, g2 = (mod[:, i * Co:(i + 1) * Co] for i in range(4))
         s2 = 4 * Co
-        h = ops.layernorm_modulate(x, shift=m1[:, :C], scale=m1[:, C:], mod_sample_stride=2 * C, rows_per_sample=Nq)
+        ln_kw = dict(shift=m1[:, :C], scale=m1[:, C:], mod_sample_stride=2 * C, rows_per_sample=Nq)
     else:
         g1 = g2 = None
         s2 = 0
-        h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
-    q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
-    if y_bf16 is None:
-        y_bf16, Nk = h, Nq
-    kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                        # [B*Nk, 2Co]: K | V  (layers.py:189)
+    fused_in = FUSED_ATTN and C in (64, 128) and P["wq"].shape[1] == C and Co % 64 == 0 and x.stride(0) % 4 == 0
+    if fused_in:
+        # LN1 (+ modulate | affine) + fc_q [+ fc_kv on the same normalised input] in ONE kernel (csrc/fused_mlp.hip):
+        # the normalised activations are never written
+        aff = {} if c is not None else dict(ln_w=P["n1"][0], ln_b=P["n1"][1])
+        if y_bf16 is None and "wqkv" in P:
+            qkv = ops.ln_linear(x, P["wqkv"], P["bqkv"], **aff, **ln_kw)
+            q, kv, Nk = qkv[:, :Co], qkv[:, Co:], Nq
+        else:
+            q = ops.ln_linear(x, P["wq"], P["bq"], **aff, **ln_kw)
+            if y_bf16 is None:                                                      # (not reached with the shipped shapes)
+                y_bf16, Nk = ops.layernorm_modulate(x, **({"w": P["n1"][0], "b": P["n1"][1]} if c is None else ln_kw)), Nq
+            kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)
+    else:
+        if c is not None:
+            h = ops.layernorm_modulate(x, **ln_kw)
+        else:
+            h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
+        q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
+        if y_bf16 is None:
+            y_bf16, Nk = h, Nq
+        kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                    # [B*Nk, 2Co]: K | V  (layers.py:189)
     if C != Co:                                                                     # shortcut(x): Conv1d dim_in -> dim_out
         from ._lib import EPI_F32
         x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)

@@ -159,6 +159,13 @@ extern "C" int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, con
     MlpArgs a{x, ldx, M, ln_w, ln_b, shift, scale, gate, mod_sample_stride, rows_per_sample, BF(w_up), b_up, BF(w_dn), b_dn};
     return ldt_ln_mlp_launch(&a, C, ST(stream));
 }
+extern "C" int ldt_ln_linear(const float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                             const float* shift, const float* scale, int64_t mod_sample_stride, int32_t rows_per_sample,
+                             const uint16_t* w, const float* bias, int32_t N, uint16_t* out, int64_t ldo, void* stream) {
+    LDT_REQUIRE(x && w && out, LDT_EARG, "ln_linear: null pointer");
+    LnLinArgs a{x, ldx, M, ln_w, ln_b, shift, scale, mod_sample_stride, rows_per_sample, BF(w), bias, N, BFM(out), ldo};
+    return ldt_ln_linear_launch(&a, C, ST(stream));
+}
 extern "C" int ldt_chamfer_pairwise(const float* x, const float* y, int32_t S, int32_t R, int32_t n, int32_t m, float* cd, void* stream) {
     LDT_REQUIRE(x && y && cd, LDT_EARG, "chamfer_pairwise: null pointer");
     return ldt_chamfer_pairwise_launch(x, y, S, R, n, m, cd, ST(stream));

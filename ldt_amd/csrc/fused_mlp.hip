@@ -64,6 +64,74 @@ __device__ __forceinline__ void stage_wdn(const bf16_t* __restrict__ w_dn, int h
     }
 }
 
+// LayerNorm (+ affine | per-sample modulate) of a wave's 32 rows, read in the MFMA accumulator layout (lane: row
+// rt*16 + lrow, channels n*16 + lq*4 .. +3); h -> bf16 -> the wave's rows of the swizzled LDS image `Hs` -> returned as the
+// MFMA operand fragments hf[ks][rt] (8 bf16 of row lrow, k = ks*32 + lq*8 ..).  `xv` keeps the fp32 inputs for the caller.
+struct LnSrc {
+    const float* x; long ldx; long M;
+    const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
+};
+template <int C>
+__device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char* Hs, int wave, int lrow, int lq,
+                                                 f32x4 (&xv)[C / 16][2], bf16x8 (&hf)[C / 32][2]) {
+    using K = MlpCfg<C>;
+    bf16x4 hpk[C / 16][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        long grow = row0 + rt * 16 + lrow;
+        grow = grow < a.M ? grow : a.M - 1;                            // tail rows: clamp, never stored
+        const float* xr = a.x + grow * a.ldx + lq * 4;
+#pragma unroll
+        for (int n = 0; n < C / 16; ++n) xv[n][rt] = *reinterpret_cast<const f32x4*>(xr + n * 16);
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < C / 16; ++n) s += (xv[n][rt][0] + xv[n][rt][1]) + (xv[n][rt][2] + xv[n][rt][3]);
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int n = 0; n < C / 16; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = xv[n][rt][j] - mean; q += d * d; }
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q / (float)C + 1e-6f);
+        const long moff = a.shift ? (grow / a.rows_per_sample) * a.mod_sample_stride : 0;
+#pragma unroll
+        for (int n = 0; n < C / 16; ++n) {
+            const int col = n * 16 + lq * 4;
+            f32x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (xv[n][rt][j] - mean) * rstd;
+            if (a.ln_w) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a.ln_w + col), b = *reinterpret_cast<const f32x4*>(a.ln_b + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = h[j] * w[j] + b[j];
+            }
+            if (a.shift) {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + moff + col), sc = *reinterpret_cast<const f32x4*>(a.scale + moff + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = h[j] * (1.f + sc[j]) + sh[j];
+            }
+            hpk[n][rt] = (bf16x4){(bf16_t)h[0], (bf16_t)h[1], (bf16_t)h[2], (bf16_t)h[3]};
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int n = 0; n < C / 16; ++n) {
+            const int hr = wave * 32 + rt * 16 + lrow;
+            *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) = hpk[n][rt];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // rows are wave-private: ordering inside the wave suffices
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int hr = wave * 32 + rt * 16 + lrow;
+            hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
+        }
+}
+
 template <int C, bool GATED>
 __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
     using K = MlpCfg<C>;
@@ -81,77 +149,22 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
     stage_wup<C>(a.w_up, 0, W0, wave, lane);                           // chunk 0 weights fly under the LayerNorm
     stage_wdn<C>(a.w_dn, 0, W0 + K::WUP_BYTES, wave, lane);
 
-    // ---- 1. LayerNorm (+ affine | modulate) of the wave's rows -> bf16 image --------------------------------------
-    // x is read in the accumulator layout (lane: row rt*16 + lrow, channels n*16 + lq*4 .. +3) so that, when there is no
-    // gate, it simply becomes the initial value of the output accumulators (x + b_dn) and is never read again.
+    // ---- 1. LayerNorm -> operand fragments of the wave's rows (kept in VGPRs; the image's LDS becomes weight set 1).
+    //         Without a gate the x values just read initialise the output accumulators (x + b_dn): x is never read again.
     f32x4 oacc[C / 16][2];
-    {
-        bf16x4 hpk[C / 16][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            long grow = row0 + rt * 16 + lrow;
-            grow = grow < a.M ? grow : a.M - 1;                        // tail rows: clamp, never stored
-            const float* xr = a.x + grow * a.ldx + lq * 4;
-            f32x4 v[C / 16];
-#pragma unroll
-            for (int n = 0; n < C / 16; ++n) v[n] = *reinterpret_cast<const f32x4*>(xr + n * 16);
-            float s = 0.f;
-#pragma unroll
-            for (int n = 0; n < C / 16; ++n) s += (v[n][0] + v[n][1]) + (v[n][2] + v[n][3]);
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            const float mean = s / (float)C;
-            float q = 0.f;
-#pragma unroll
-            for (int n = 0; n < C / 16; ++n)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = v[n][j] - mean; q += d * d; }
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-            const float rstd = rsqrtf(q / (float)C + 1e-6f);
-            const long moff = a.shift ? (grow / a.rows_per_sample) * a.mod_sample_stride : 0;
-#pragma unroll
-            for (int n = 0; n < C / 16; ++n) {
-                const int col = n * 16 + lq * 4;
-                f32x4 h;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = (v[n][j] - mean) * rstd;
-                if (a.ln_w) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.ln_w + col), b = *reinterpret_cast<const f32x4*>(a.ln_b + col);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = h[j] * w[j] + b[j];
-                }
-                if (a.shift) {
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + moff + col), sc = *reinterpret_cast<const f32x4*>(a.scale + moff + col);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = h[j] * (1.f + sc[j]) + sh[j];
-                }
-                hpk[n][rt] = (bf16x4){(bf16_t)h[0], (bf16_t)h[1], (bf16_t)h[2], (bf16_t)h[3]};
-                if (GATED) {
-                    oacc[n][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + col);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) oacc[n][rt][j] = v[n][j] + b4[j];
-                }
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int n = 0; n < C / 16; ++n) {
-                const int hr = wave * 32 + rt * 16 + lrow;
-                *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) = hpk[n][rt];
-            }
-    }
-    // the wave's rows as MFMA operand fragments, for the whole kernel (rows are wave-private: no barrier needed to read)
     bf16x8 hf[C / 32][2];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const LnSrc src{a.x, a.ldx, a.M, a.ln_w, a.ln_b, a.shift, a.scale, a.mod_sample_stride, a.rows_per_sample};
+        ln_rows_to_frags<C>(src, row0, Hs, wave, lrow, lq, oacc, hf);
 #pragma unroll
-    for (int ks = 0; ks < C / 32; ++ks)
+        for (int n = 0; n < C / 16; ++n) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + n * 16 + lq * 4);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int hr = wave * 32 + rt * 16 + lrow;
-            hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oacc[n][rt][j] = GATED ? 0.f : oacc[n][rt][j] + b4[j];
         }
+    }
 
     // ---- 2. hidden chunks ------------------------------------------------------------------------------------------
 #ifdef MLP_DBG_NCH
@@ -249,6 +262,88 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm + one linear layer:  out[M][N] (bf16) = LN(x)[affine | modulated] . W^T + b   — the attention half's input side
+// (model/layers.py:218 / :225: fc_q, and fc_kv too when the block attends to its own normalised input).  Same skeleton as
+// the MLP kernel: 32 rows per wave as register fragments, W streamed in chunks of 64 output channels (double-buffered
+// LDS-DMA), the bf16 result chunk staged through the wave's LDS rows so that whole 128-B row pieces are stored.
+template <int C>
+__global__ __launch_bounds__(256, 2) void ln_linear_kernel(const LnLinArgs a) {
+    using K = MlpCfg<C>;
+    extern __shared__ __attribute__((aligned(16))) char mlp_smem[];
+    char* Hs = mlp_smem;                                               // h image, later weight set 1
+    char* Us = Hs + K::H_BYTES;                                        // output staging: 128 rows x 64 bf16
+    char* W0 = Us + K::U_BYTES;                                        // weight set 0
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * 128 + wave * 32;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nch = a.N / 64;
+    stage_wup<C>(a.w, 0, W0, wave, lane);
+    f32x4 xv[C / 16][2];
+    bf16x8 hf[C / 32][2];
+    {
+        const LnSrc src{a.x, a.ldx, a.M, a.ln_w, a.ln_b, a.shift, a.scale, a.mod_sample_stride, a.rows_per_sample};
+        ln_rows_to_frags<C>(src, row0, Hs, wave, lrow, lq, xv, hf);
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* Wu = (ch & 1) ? Hs : W0;
+        if (ch + 1 < nch) stage_wup<C>(a.w, (ch + 1) * 64, (ch & 1) ? W0 : Hs, wave, lane);
+        f32x4 uacc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+            const int c = ks * 4 + lq;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int wr = t * 16 + lrow;
+                wf[t] = *reinterpret_cast<const bf16x8*>(Wu + wr * K::ROWB + ((c ^ swz<K::CB>(wr)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch * 64 + t * 16 + lq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 v = uacc[t][rt];
+                const bf16x4 pk = {(bf16_t)(v[0] + b4[0]), (bf16_t)(v[1] + b4[1]), (bf16_t)(v[2] + b4[2]), (bf16_t)(v[3] + b4[3])};
+                const int ur = wave * 32 + rt * 16 + lrow;
+                *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                               // 8 rows x 128 B per pass, 16 B per lane
+            const int r = it * 8 + (lane >> 3), cidx = lane & 7;
+            const int ur = wave * 32 + r;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((cidx ^ swz<8>(ur)) << 4));
+            if (row0 + r < a.M) *reinterpret_cast<bf16x8*>(a.out + (row0 + r) * a.ldo + ch * 64 + cidx * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // staging rows are rewritten by the next chunk
+    }
+}
+
+template <int C>
+int launch_ln_linear(const LnLinArgs* a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear_kernel<C>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C>::LDS);
+        if (e != hipSuccess) { ldt_set_error("ln_linear: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ln_linear_kernel<C>, dim3((unsigned)((a->M + 127) / 128)), dim3(256), MlpCfg<C>::LDS, st, *a);
+    return ldt_check_launch("ln_linear");
+}
+
 template <int C, bool GATED>
 int launch_mlp(const MlpArgs* a, hipStream_t st) {
     static bool attr_set = false;
@@ -279,4 +374,18 @@ int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st) {
                 LDT_EALIGN, "ln_mlp: operands must be 16-byte aligned");
     if (a->gate) return C == 128 ? launch_mlp<128, true>(a, st) : launch_mlp<64, true>(a, st);
     return C == 128 ? launch_mlp<128, false>(a, st) : launch_mlp<64, false>(a, st);
+}
+
+int ldt_ln_linear_launch(const LnLinArgs* a, int C, hipStream_t st) {
+    LDT_REQUIRE(a->M > 0 && a->M < (1L << 31) * 128, LDT_ESHAPE, "ln_linear: bad row count %ld", a->M);
+    LDT_REQUIRE(C == 64 || C == 128, LDT_ESHAPE, "ln_linear: the fused kernel is built for 64 or 128 channels (got %d)", C);
+    LDT_REQUIRE(a->N > 0 && a->N % 64 == 0, LDT_ESHAPE, "ln_linear: N=%d must be a multiple of 64", a->N);
+    LDT_REQUIRE(a->ldx >= C && a->ldx % 4 == 0 && ldt_aligned16(a->x) && a->ldo >= a->N && a->ldo % 8 == 0 && ldt_aligned16(a->out) &&
+                ldt_aligned16(a->w) && (!a->bias || ldt_aligned16(a->bias)), LDT_EALIGN, "ln_linear: rows must be 16-byte aligned");
+    LDT_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr) && (a->shift == nullptr) == (a->scale == nullptr), LDT_EARG,
+                "ln_linear: affine / modulation vectors come in pairs");
+    LDT_REQUIRE(!a->shift || (a->rows_per_sample > 0 && a->mod_sample_stride % 4 == 0 && ldt_aligned16(a->shift) && ldt_aligned16(a->scale)),
+                LDT_EARG, "ln_linear: modulation needs rows_per_sample > 0 and 16-byte aligned vectors");
+    LDT_REQUIRE(!a->ln_w || (ldt_aligned16(a->ln_w) && ldt_aligned16(a->ln_b)), LDT_EALIGN, "ln_linear: affine vectors must be 16-byte aligned");
+    return C == 128 ? launch_ln_linear<128>(a, st) : launch_ln_linear<64>(a, st);
 }

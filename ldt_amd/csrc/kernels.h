@@ -91,6 +91,14 @@ struct MlpArgs {
     const bf16_t* w_dn; const float* b_dn;             // [C][4C], [C]
 };
 int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st);
+// fused LayerNorm + linear (bf16 out) for narrow blocks (fused_mlp.hip)
+struct LnLinArgs {
+    const float* x; long ldx; long M;
+    const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
+    const bf16_t* w; const float* bias; int N;          // [N][C], [N] (nullable)
+    bf16_t* out; long ldo;
+};
+int ldt_ln_linear_launch(const LnLinArgs* a, int C, hipStream_t st);
 int ldt_chamfer_pairwise_launch(const float* x, const float* y, int S, int R, int n, int m, float* cd, hipStream_t st);
 int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, int m, int pairwise, float* out, hipStream_t st);
 int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, hipStream_t s);

@@ -272,3 +272,16 @@ def attention_oproj_resid_(q, k, v, B, H, Nq, Nk, head_dim, wo, bo, x, gate=None
                                           k.stride(0) * Nk, B, H, Nq, Nk, head_dim, _p(wo), _p(bo), _p(x), x.stride(0),
                                           _p(gate), gate_sample_stride, stream_ptr()), "ldt_attention_oproj_resid")
     return x
+
+
+def ln_linear(x, w, bias=None, ln_w=None, ln_b=None, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=0):
+    """bf16 [M,N] = LN(x)[affine | modulated] @ w[N,C]^T + bias for C in {64, 128} channels, N % 64 == 0 (one fused kernel)."""
+    _need(x, torch.float32, "x"); _rowmajor(x, "x"); _need(w, torch.bfloat16, "w")
+    M, Cc = x.shape
+    N = w.shape[0]
+    if w.shape[1] != Cc or not w.is_contiguous():
+        raise ValueError("ln_linear: w must be dense bf16 [N][C]")
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib().ldt_ln_linear(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), mod_sample_stride, rows_per_sample,
+                              _p(w), _p(bias), N, _p(out), N, stream_ptr()), "ldt_ln_linear")
+    return out
