@@ -178,6 +178,20 @@ class Compressor(nn.Module):
         self.init_set = InitialSet(self.hidden_dim, self.max_outputs)
         self._pack, self._pack_key = None, None
         self.decode_chunk = 128          # samples per decode pass (activations ~7 MB/sample at 2048 points)
+        # True: consume the CPU generator exactly as the reference does (B randperms per InitialSet call even when all rows
+        # are kept; posterior noise drawn with CPU randn and copied over) so that seeded runs stay stream-aligned with it.
+        # False (default): no idle randperms, posterior noise from the device-side Philox keyed by ONE CPU draw — the CPU
+        # draws + copies are ~2x the GPU time of an encode.  Explicit `post_noise=` / `given_eps=` work in both modes.
+        self.reference_rng = False
+
+    def _presence(self, B, num_points):
+        """InitialSet's row subset (Compressor/ops.py:6-14): B CPU `randperm(max_outputs) < num_points` masks, or None when
+        every row is kept.  The reference draws the B permutations even then (quirk Q9) — 10 us each, which is half of a
+        1024-cloud decode on this path — so that burn is only reproduced under `reference_rng`."""
+        if num_points == self.max_outputs and not self.reference_rng:
+            return None
+        presence = [torch.randperm(self.max_outputs) < num_points for _ in range(B)]
+        return torch.stack(presence, 0) if num_points != self.max_outputs else None
 
     def init(self):
         """Network.py:163-165 — marks ActNorm initialised (call after loading a checkpoint)."""
@@ -225,11 +239,8 @@ class Compressor(nn.Module):
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("Compressor.sample: parameters on %s; the HIP path has no CPU fallback" % dev)
-        # InitialSet.forward draws B randperms on the CPU generator even when every row is kept (quirk Q9,
-        # Compressor/ops.py:12): keep the generator stream aligned with the reference.
         if keep_mask is None:
-            presence = [torch.randperm(self.max_outputs) < num_points for _ in range(B)]
-            keep_mask = torch.stack(presence, 0) if num_points != self.max_outputs else None
+            keep_mask = self._presence(B, num_points)
         if given_eps is None:                                            # Network.py:259-260
             given_eps = torch.randn((B, self.z_scales, self.n_layers * self.z_dim)).to(dev)
         eps = given_eps.to(dev, torch.float32).contiguous()
@@ -291,11 +302,14 @@ class Compressor(nn.Module):
         B, N, _ = x.shape
         T, D, z, L = self.z_scales, self.hidden_dim, self.z_dim, self.n_layers
         npts = self.outsize if num_points is None else num_points
-        # CPU generator stream in the reference's order: B randperms (InitialSet, :215) then one randn per level (:220)
-        presence = [torch.randperm(self.max_outputs) < npts for _ in range(B)]
-        keep_mask = torch.stack(presence, 0) if npts != self.max_outputs else None
+        # reference order on the CPU generator: B randperms (InitialSet, :215) then one randn per level (:220)
+        keep_mask = self._presence(B, npts)
         if post_noise is None:
-            post_noise = [torch.randn((B, z, T)).transpose(1, 2) for _ in range(L)]
+            if self.reference_rng:
+                post_noise = [torch.randn((B, z, T)).transpose(1, 2) for _ in range(L)]
+            else:                                                    # one CPU draw keys a device-side Philox stream per level
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                post_noise = [ops.philox_normal((B, T, z), dev, seed, step=j) for j in range(L)]
         P = self.packed()
         pts = x.to(dev, torch.float32).contiguous()
         k = N // T * 2                                                              # Network.py:195

@@ -144,3 +144,47 @@ def test_encode_decode_roundtrip_shapes_full_size():
         assert torch.equal(r1["all_eps"], r2["all_eps"])
         dec = comp.decode(r1["all_eps"], 2048)
         assert rel_mse(dec.cpu(), r1["set"].cpu()) < 1e-6            # decode(all_eps) reproduces the reconstruction
+
+
+def test_compressor_rng_modes(tiny_cfg):
+    """`reference_rng=True` consumes the CPU generator exactly as the reference does — B randperms per InitialSet call
+    (quirk Q9, even when every row is kept) then one (B, z, T) randn per level (Network.py:26-29,215-220) — so a seeded run
+    equals the run with those draws injected and leaves the generator in the same state.  The default mode keys a
+    device-side Philox stream with ONE CPU draw: seeded runs repeat, and explicit noise gives identical results in both."""
+    import ldt_amd
+    a, _ = load_golden("compressor_fwd_tiny")
+    _, csd = load_golden("trainer_sample_tiny")
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    comp.load_state_dict(csd["c"], strict=True)
+    comp = comp.cuda()
+    pts = a["pts"].cuda()
+    B, T, z, L = pts.shape[0], comp.z_scales, comp.z_dim, comp.n_layers
+    comp.reference_rng = True
+    torch.manual_seed(42)
+    out_ref = comp(pts)["all_eps"]
+    state_after = torch.get_rng_state()
+    torch.manual_seed(42)
+    for _ in range(B):
+        torch.randperm(comp.max_outputs)
+    noise = [torch.randn((B, z, T)).transpose(1, 2) for _ in range(L)]
+    assert torch.equal(torch.get_rng_state(), state_after)
+    assert torch.equal(comp(pts, post_noise=noise)["all_eps"], out_ref)
+    torch.manual_seed(42)
+    comp.sample((B, 64), given_eps=out_ref)
+    torch.manual_seed(42)
+    for _ in range(B):
+        torch.randperm(comp.max_outputs)
+    expect_state = torch.get_rng_state()
+    torch.manual_seed(42)
+    comp.sample((B, 64), given_eps=out_ref)
+    assert torch.equal(torch.get_rng_state(), expect_state)
+    comp.reference_rng = False
+    assert torch.equal(comp(pts, post_noise=noise)["all_eps"], out_ref)          # explicit noise: mode-independent
+    torch.manual_seed(7)
+    e1 = comp(pts)["all_eps"]
+    torch.manual_seed(7)
+    e2 = comp(pts)["all_eps"]
+    assert torch.equal(e1, e2) and not torch.equal(e1, out_ref) and torch.isfinite(e1).all()
+    s0 = torch.get_rng_state()
+    comp.sample((B, 64), given_eps=e1)                                          # no idle randperms in the default mode
+    assert torch.equal(torch.get_rng_state(), s0)
