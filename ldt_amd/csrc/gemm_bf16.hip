@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
             } else {
                 if (EPI == EPI_GELU_BF16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                    for (int r = 0; r < 4; r += 2) {                 // two lanes of the polynomial per v_pk_* instruction
+                        const f32x2 gg = gelu_erf_fast2((f32x2){v[r], v[r + 1]});
+                        v[r] = gg[0]; v[r + 1] = gg[1];
+                    }
                 }
                 if (EPI == EPI_RELU_BF16) {
                     if (a.skip) {
@@ -298,7 +301,10 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
                 for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
                 if (EPI == EPI_GELU_BF16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_fast(v[r]);
+                    for (int r = 0; r < 4; r += 2) {                 // two lanes of the polynomial per v_pk_* instruction
+                        const f32x2 gg = gelu_erf_fast2((f32x2){v[r], v[r + 1]});
+                        v[r] = gg[0]; v[r + 1] = gg[1];
+                    }
                 }
                 if (EPI == EPI_RELU_BF16) {
                     if (a.skip) {
