@@ -518,7 +518,8 @@ static int launch_256(const GemmArgs* a, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-    const int grid = tiles < LDT_NUM_CUS ? tiles : LDT_NUM_CUS;         // one persistent workgroup per CU
+    static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
+    const int grid = tiles < cap ? tiles : cap;                          // one persistent workgroup per CU
     hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256");
 }
