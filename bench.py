@@ -99,7 +99,8 @@ def roofline_pass(trainer, cfg, B, reps=3):
     T, z, D, F = cfg.score.z_scale, cfg.score.z_dim, cfg.score.hidden_size, 4 * cfg.score.hidden_size
     t = torch.linspace(1.0, 1e-6, 8).to(dev)
     _, mod = model.time_table(t)
-    plan = model.plan(B, T, mod, model.n_mod, 0)
+    folded = model.can_fold(B, T)                       # the same decision sample_discrete takes for this (B, T)
+    plan = model.plan(B, T, mod, model.n_mod, 0, fold=model.fold_table(mod) if folded else None)
     x = torch.randn(B, T, z, device=dev)
     out = torch.empty_like(x)
     ncls = len(_lib.PROF_CLASSES)
@@ -127,13 +128,14 @@ def roofline_pass(trainer, cfg, B, reps=3):
             k["tflops"] = round(flops[name] / (avg * 1e-3) / 1e12, 2)
         kernels[name] = k
     dom = max(("gemm_qkv", "gemm_gelu", "gemm_resid"), key=lambda n: kernels[n]["ms_per_forward"])
-    # symbols as rocprofv3 prints them (template argument = epilogue id: 1 BF16, 2 GELU_BF16, 4 RESID_F32)
-    sym = {"gemm_qkv": "gemm_bf16_nt_256_kernel<1>", "gemm_gelu": "gemm_bf16_nt_256_kernel<2>",
-           "gemm_resid": "gemm_bf16_nt_256_kernel<4>"}[dom]
+    # symbols as rocprofv3 prints them: <epilogue id (1 BF16, 2 GELU_BF16, 4 RESID_F32), LN folding (0 none, 1 producer:
+    # also emits x(1+scale) + row statistics, 2 consumer: applies the LayerNorm in its epilogue)>
+    sym = {"gemm_qkv": "gemm_bf16_nt_256_kernel<1, %d>" % (2 if folded else 0), "gemm_gelu": "gemm_bf16_nt_256_kernel<2, %d>" % (2 if folded else 0),
+           "gemm_resid": "gemm_bf16_nt_256_kernel<4, %d>" % (1 if folded else 0)}[dom]
     ach = kernels[dom]["tflops"]
     roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(sym), "kernel": sym,
-            "flops_per_launch": flops[dom], "avg_launch_ms": kernels[dom]["avg_ms"]}
+            "flops_per_launch": flops[dom], "avg_launch_ms": kernels[dom]["avg_ms"], "ln_folding": folded}
     a = kernels["attention"]
     abytes = 4.0 * M * D * 2                                               # read Q,K,V + write O in bf16
     gbs = abytes / (a["avg_ms"] * 1e-3) / 1e9

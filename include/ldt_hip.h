@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 5
+#define LDT_ABI_VERSION 6
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -58,6 +58,26 @@ int ldt_gemm_bf16(int32_t epilogue, const uint16_t* X, int64_t ldx, const uint16
                   const float* gate, int64_t gate_sample_stride, int32_t rows_per_sample,
                   const int32_t* step_ptr, int64_t gate_step_stride,
                   int32_t M, int32_t N, int32_t K, void* stream);
+
+/* ---- LayerNorm folded into the neighbouring GEMMs (batch-shared AdaLN modulation) ------------------------------
+ * The reference's  x = x + gate * fc(...) ; h = LN(x) * (1 + scale) + shift ; y = W h + b  (model/layers.py:218-219 with
+ * :136-137 and tools/utils.py:127-133) without a LayerNorm pass over x.  With mu, r = mean and rstd of a row of x:
+ *     y = r * (W xs) - r * mu * S + C,   xs = x (1 + scale),  S[n] = sum_k (1 + scale[k]) W[n][k],  C[n] = sum_k shift[k] W[n][k] + b[n].
+ * ldt_gemm_resid_lnstats (producer):  out = out + gate * (X W^T + bias) in place (LDT_EPI_RESID_F32), plus
+ *     xs[M][N] = bf16(out * (1 + ln_scale[n])) and stats_out[N/256][M][2] = per-row (sum, sum of squares) of out over
+ *     each 256-column tile (deterministic: no atomics).
+ * ldt_gemm_lnfold (consumer):  out bf16 = epi(r * (Xs W^T) - r * mu * fold_S + fold_C), epilogue LDT_EPI_BF16 or
+ *     LDT_EPI_GELU_BF16; the row statistics are those of the K = stats_parts*256 input channels (K <= 1024).
+ * ln_scale / fold_S / fold_C / gate are addressed base + (*step_ptr) * their step stride (step_ptr NULL = 0).
+ * M, N multiples of 256, K >= 256; the host builds S and C in fp32 from the SAME bf16 W the GEMM reads. */
+int ldt_gemm_resid_lnstats(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias,
+                           float* out, int64_t ldo, const float* gate, int64_t gate_sample_stride,
+                           int32_t rows_per_sample, const float* ln_scale, uint16_t* xs, int64_t ldxs,
+                           float* stats_out, const int32_t* step_ptr, int64_t gate_step_stride,
+                           int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, void* stream);
+int ldt_gemm_lnfold(int32_t epilogue, const uint16_t* Xs, int64_t ldx, const uint16_t* W, int64_t ldw,
+                    const float* stats_in, const float* fold_S, const float* fold_C, uint16_t* out, int64_t ldo,
+                    const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, void* stream);
 
 /* ---- LayerNorm(eps 1e-6) [+affine] [+AdaLN modulate] -> bf16 -----------------------------------------
  * y = LN(x)[*w+b] * (1 + scale[s]) + shift[s].  tools/utils.py:127-133 + model/layers.py:136-137,218-219.
@@ -201,6 +221,11 @@ typedef struct ldt_score_plan {
     uint16_t* QKV;   /* [M][3*hidden]    */
     uint16_t* Ob;    /* [M][hidden]  == [B][H][T][Dh] */
     uint16_t* U;     /* [M][mlp_hidden]  */
+    /* Optional LN folding (see ldt_gemm_resid_lnstats): fold[step][blocks][S_qkv 3h | C_qkv 3h | S_up mlp | C_up mlp] fp32
+       built by the host from mod and the packed weights; stats = fp32 scratch [hidden/256][M][2].  Used when both are
+       non-NULL, mod_sample_stride == 0, no cross-attention, M % 256 == 0, hidden % 256 == 0 <= 1024, mlp_hidden % 256 == 0;
+       otherwise the LayerNorm kernels run (the host passes fold only where whole 256x256 tiles fill the chip). */
+    const float* fold; int64_t fold_step_stride; float* stats;
 } ldt_score_plan;
 
 /* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */

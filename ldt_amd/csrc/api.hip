@@ -2,6 +2,7 @@
 // host-side orchestrators that enqueue the whole Score forward / reverse-SDE loop on one HIP stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -55,6 +56,26 @@ extern "C" int ldt_gemm_bf16(int32_t epilogue, const uint16_t* X, int64_t ldx, c
     GemmArgs a{BF(X), ldx, BF(W), ldw, bias, out, ldo, resid, ldr, BF(skip), ldskip, gate, gate_sample_stride,
                rows_per_sample, step_ptr, gate_step_stride, M, N, K};
     return ldt_gemm_launch(epilogue, &a, ST(stream));
+}
+
+extern "C" int ldt_gemm_resid_lnstats(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias,
+                                      float* out, int64_t ldo, const float* gate, int64_t gate_sample_stride,
+                                      int32_t rows_per_sample, const float* ln_scale, uint16_t* xs, int64_t ldxs,
+                                      float* stats_out, const int32_t* step_ptr, int64_t gate_step_stride,
+                                      int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, void* stream) {
+    LDT_REQUIRE(X && W && out && xs && ln_scale && stats_out, LDT_EARG, "gemm_resid_lnstats: null pointer");
+    GemmArgs a{BF(X), ldx, BF(W), ldw, bias, out, ldo, out, ldo, nullptr, 0, gate, gate_sample_stride, rows_per_sample, step_ptr,
+               gate_step_stride, M, N, K, BFM(xs), ldxs, ln_scale, ln_step_stride, stats_out};
+    return ldt_gemm_lnfold_launch(EPI_RESID_F32, &a, ST(stream));
+}
+
+extern "C" int ldt_gemm_lnfold(int32_t epilogue, const uint16_t* Xs, int64_t ldx, const uint16_t* W, int64_t ldw,
+                               const float* stats_in, const float* fold_S, const float* fold_C, uint16_t* out, int64_t ldo,
+                               const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, void* stream) {
+    LDT_REQUIRE(Xs && W && out && stats_in && fold_S && fold_C, LDT_EARG, "gemm_lnfold: null pointer");
+    GemmArgs a{BF(Xs), ldx, BF(W), ldw, nullptr, out, ldo, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, N, K,
+               nullptr, 0, nullptr, 0, nullptr, stats_in, K / 256, fold_S, fold_C, fold_step_stride};
+    return ldt_gemm_lnfold_launch(epilogue, &a, ST(stream));
 }
 
 extern "C" int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, const float* w,
@@ -218,6 +239,12 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     LDT_REQUIRE(x && eps_out, LDT_EARG, "score: null x/out");
     const int D = p->hidden, T = p->tokens, M = p->batch * p->tokens, F = p->mlp_hidden;
     const long sstr = p->mod_sample_stride, tstr = p->mod_step_stride;
+    // LN folding (gemm_bf16.hip): with batch-shared modulation (unconditional sampling) the LayerNorm + modulate between a
+    // residual GEMM and the next projection is folded into the two GEMMs' epilogues; the host supplies the per-step
+    // S / C tables (plan->fold) when that pays (whole 256x256 tiles that fill the chip: Score.can_fold).
+    bool fold = p->fold && p->stats && sstr == 0 && M % 256 == 0 && D % 256 == 0 && D <= 1024 && F % 256 == 0;
+    for (int l = 0; l < p->blocks && fold; ++l) fold = !p->kv_cond[l];
+    const long fstep = p->fold_step_stride, fblk = 6L * D + 2L * F;   // per block: S_qkv[3D] | C_qkv[3D] | S_up[F] | C_up[F]
     // ln_in (score.py:136-137): latents fp32 -> bf16 (K padded) -> X fp32
     LAUNCH(LDT_PROF_OTHER, ldt_cast_pad_launch(x, p->z_dim, BFM(p->xin), p->z_pad, M, p->z_dim, p->z_pad, s));
     {
@@ -226,6 +253,15 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     }
     for (int l = 0; l < p->blocks; ++l) {                       // score.py:148-149, layers.py:212-219
         const float* m = p->mod + (long)l * 6 * D;              // shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
+        const float* fl = fold ? p->fold + (long)l * fblk : nullptr;
+        if (fold && l > 0) {                                    // Hb = x (1 + scale_msa) and the row statistics came from block l-1's mlp.out
+            GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, nullptr, p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, 3 * D, D,
+                        nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl, fl + 3L * D, fstep};
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
+            AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
+                        BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
+            LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        } else {
         LnArgs n1{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n1, s));
         if (p->kv_cond[l]) {                                    // cross-attention: q from the modulated x, K|V from the condition
@@ -241,6 +277,21 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+        }
+        }
+        if (fold) {
+            // fc_o + gate + residual, also emitting Hb = x (1 + scale_mlp) and the row statistics; mlp.fc consumes them
+            GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D,
+                        BFM(p->Hb), D, m + 4 * D, tstr, p->stats};
+            LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
+            GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, nullptr, p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, F, D,
+                        nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl + 6L * D, fl + 6L * D + F, fstep};
+            LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
+            GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F,
+                        BFM(p->Hb), D, m + 6 * D + D, tstr, p->stats};      // next block's scale_msa
+            if (l + 1 < p->blocks) LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
+            else LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
+            continue;
         }
         GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
         LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));

@@ -281,24 +281,75 @@ __device__ __forceinline__ void v2_epilogue_edge(const GemmArgs& a, f32x4 (&acc)
     }
 }
 
+// sum over the 16 lanes of a DPP row (all 16 end up with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// LN folding (FOLD): the LayerNorm + AdaLN modulate between a residual GEMM and the next projection never runs as a
+// kernel.  With h = LN(x)(1 + sc) + sh, r = rstd(x), mu = mean(x):
+//     h . W^T + b  =  r * ( xs . W^T )  -  r * mu * S  +  C,     xs = x (1 + sc),  S_n = sum_k (1 + sc_k) W_nk,  C_n = sum_k sh_k W_nk + b_n
+//   FOLD_PRODUCER (EPI_RESID_F32): besides x_new the epilogue stores xs = bf16(x_new (1 + sc)) and, per row, the partial
+//     (sum, sum of squares) of x_new over this tile's 256 columns  -> stats_out[n0/256][M][2]  (DPP row sums, the four
+//     column waves combined through LDS: one 8-B value per row and tile, summed in a fixed order — no atomics).
+//   FOLD_CONSUMER (EPI_BF16 / EPI_GELU_BF16): X = xs; the tile's 256 rows x stats_parts partials are fetched by one
+//     LDS-DMA piece per wave during the main loop (into the unused tail of the bf16 staging areas), r / -r mu are
+//     formed per lane at the start of the epilogue and y = r acc + (-r mu S + C) replaces acc + bias.
+//   S, C are batch-invariant per-step tables built by the host in fp32 from the same bf16 W the MFMAs read.
+enum { FOLD_NONE = 0, FOLD_PRODUCER = 1, FOLD_CONSUMER = 2 };
+#define V2_STATS_OFF 2304            /* bf16 staging uses 16 rows x 144 B of each wave's 4 KiB */
+
 // interior tiles: per-wave LDS staging (16 output rows per pass) -> 16 B per lane over whole rows
-template <int EPI>
+template <int EPI, int FOLD>
 __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
-                                                   int lane, int lrow, int lchk, const float* gate, char* reg) {
+                                                   int lane, int lrow, int lchk, const float* gate, char* reg, char* stage_base,
+                                                   const float* fold_S, const float* fold_C, const float* ln_scale) {
     const int mb = m0 + grp * 128, nb = n0 + wn * 64;
     f32x4 bias4[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-        bias4[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bias4[ni] = (a.bias && FOLD != FOLD_CONSUMER) ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
         constexpr int RS = 128 + 16;                              // staged row: 64 bf16 + 16 B pad
+        f32x4 s4[4];
+        float rr[8], nm[8];
+        if (FOLD == FOLD_CONSUMER) {
+            const float invk = 1.0f / (float)a.K;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int R = grp * 128 + mi * 16 + lrow;         // row inside the tile; piece q = part*2 + (R >> 7) sits in wave q's area
+                float s1 = 0.f, s2 = 0.f;
+                for (int pp = 0; pp < a.stats_parts; ++pp) {
+                    const f32x2 t = *reinterpret_cast<const f32x2*>(stage_base + (pp * 2 + (R >> 7)) * 4096 + V2_STATS_OFF + (R & 127) * 8);
+                    s1 += t[0]; s2 += t[1];
+                }
+                const float mean = s1 * invk;
+                const float var = fmaxf(s2 * invk - mean * mean, 0.f);
+                rr[mi] = rsqrtf(var + 1e-6f);
+                nm[mi] = -mean * rr[mi];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                s4[ni] = *reinterpret_cast<const f32x4*>(fold_S + nb + ni * 16 + lchk * 4);
+                bias4[ni] = *reinterpret_cast<const f32x4*>(fold_C + nb + ni * 16 + lchk * 4);
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[ni][mi];
+                if (FOLD == FOLD_CONSUMER) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * rr[mi] + (nm[mi] * s4[ni][r] + bias4[ni][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                }
                 if (EPI == EPI_GELU_BF16) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {                 // two lanes of the polynomial per v_pk_* instruction
@@ -332,6 +383,13 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
         const bool has_gate = (EPI == EPI_RESID_F32) && gate;
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
         if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
+        float rs1[8], rs2[8];                                     // FOLD_PRODUCER: lanes with (lane & 15) < 4 keep row (lane&15)*4 + (lane>>4) of pass mi
+        if (FOLD == FOLD_PRODUCER) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ln_scale + nb + ch * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc4[r] = 1.0f + t[r];
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
@@ -342,6 +400,7 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
                 *reinterpret_cast<f32x4*>(reg + lrow * 256 + (((ni * 4 + lchk) ^ lrow) << 4)) = v;
             }
             const long mrow0 = mb + mi * 16;
+            float k1 = 0.f, k2 = 0.f;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + (lane >> 4);
@@ -355,12 +414,40 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
                     for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                 }
                 if (EPI != EPI_DISCARD || a.M < 0) *reinterpret_cast<f32x4*>(o) = v;
+                if (FOLD == FOLD_PRODUCER) {
+                    const bf16x4 pk = {(bf16_t)(v[0] * sc4[0]), (bf16_t)(v[1] * sc4[1]), (bf16_t)(v[2] * sc4[2]), (bf16_t)(v[3] * sc4[3])};
+                    *reinterpret_cast<bf16x4*>(a.xs + (mrow0 + row) * a.ldxs + nb + ch * 4) = pk;
+                    const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                    const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                    const bool keep = (lane & 15) == it;
+                    k1 = keep ? s1 : k1; k2 = keep ? s2 : k2;
+                }
             }
+            rs1[mi] = k1; rs2[mi] = k2;
         }
+        if (FOLD == FOLD_PRODUCER) {
+            // the wave's 128 rows x (sum, sumsq) over its 64 columns -> head of its staging area; the four column waves of a
+            // row group are then added in the fixed order wn = 0..3 by one thread per row
+            if ((lane & 15) < 4) {
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+                    *reinterpret_cast<f32x2*>(reg + (mi * 16 + (lane & 15) * 4 + (lane >> 4)) * 8) = (f32x2){rs1[mi], rs2[mi]};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V2_BARRIER();
+            const int tid = threadIdx.x;
+            if (tid < 256) {
+                const char* src = stage_base + (tid >> 7) * 4 * 4096 + (tid & 127) * 8;
+                f32x2 t = *reinterpret_cast<const f32x2*>(src);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) { const f32x2 u = *reinterpret_cast<const f32x2*>(src + w * 4096); t[0] += u[0]; t[1] += u[1]; }
+                *reinterpret_cast<f32x2*>(a.stats_out + ((long)(n0 >> 8) * a.M + m0 + tid) * 2) = t;
+            }
+        }                                                         // (the staging areas are next written a whole main loop later)
     }
 }
 
-template <int EPI>
+template <int EPI, int FOLD = FOLD_NONE>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x;
@@ -428,10 +515,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + lrow; woff[i] = V2_OPER_BYTES + r * 64 + ((lchk ^ v2_swz(r)) << 4); }
 
-    // stores a wave leaves in flight after one STAGED epilogue (its loads are consumed, hence retired, inside it)
-    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16 : 32;
+    // stores a wave leaves in flight after one STAGED epilogue (its loads are consumed, hence retired, inside it);
+    // a smaller count only waits longer (FOLD_PRODUCER: 32 x + 32 xs + 1 stats stores exceed the 6-bit counter)
+    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
+                             : (FOLD == FOLD_PRODUCER) ? 57 : 32;
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
+    const float* ln_scale = (FOLD == FOLD_PRODUCER) ? a.ln_scale + (long)step * a.ln_step_stride : nullptr;
+    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
+    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
     const bool aligned = (a.ldo % 8 == 0) && (EPI != EPI_RESID_F32 || a.ldr % 4 == 0) && (EPI != EPI_RELU_BF16 || !a.skip || a.lds_ % 4 == 0);
     char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
 
@@ -459,6 +552,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #if V2_NEXT_IN_L
             next_w(sw);
 #endif
+            if (FOLD == FOLD_CONSUMER && v == 2 && wave < 2 * a.stats_parts) {
+                // row statistics of this tile: piece q = wave = part*2 + half -> 128 rows x 8 B, into the tail of this wave's
+                // staging area.  Issued two sub-tiles into the tile (every wave is past the previous epilogue's reads: >= 8
+                // barriers), retired by the counted wait of sub-tile 3 and read only in the epilogue (K >= 256).
+                const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
+            }
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -500,7 +601,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
         if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
 
         prev_staged = (m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned;
-        if (prev_staged) v2_epilogue_staged<EPI>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg);
+        if (prev_staged || FOLD != FOLD_NONE)                            // FOLD: the launcher admits interior, aligned tiles only
+            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, fold_S, fold_C, ln_scale);
         else v2_epilogue_edge<EPI>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail batches before exit
@@ -508,11 +610,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #undef ISSUE_W
 }
 
-template <int EPI>
+template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI, FOLD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
         if (e != hipSuccess) { ldt_set_error("gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
@@ -520,8 +622,32 @@ static int launch_256(const GemmArgs* a, hipStream_t stream) {
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int grid = tiles < cap ? tiles : cap;                          // one persistent workgroup per CU
-    hipLaunchKernelGGL(gemm_bf16_nt_256_kernel<EPI>, dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256");
+}
+
+// LN-folding launches: always the 256-tile kernel, interior + aligned tiles only (checked here, assumed by the kernel).
+int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
+    LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K >= 256 && a->M % 256 == 0 && a->N % 256 == 0 && a->K % BK == 0, LDT_ESHAPE,
+                "gemm_lnfold: M=%d N=%d must be multiples of 256 and K=%d >= 256, K %% 64 == 0", a->M, a->N, a->K);
+    LDT_REQUIRE(a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldx >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && ldt_aligned16(a->X) &&
+                ldt_aligned16(a->W) && ldt_aligned16(a->out), LDT_EALIGN, "gemm_lnfold: operands must be 16-byte aligned (ldx=%ld ldw=%ld ldo=%ld)",
+                a->ldx, a->ldw, a->ldo);
+    if (epi == EPI_RESID_F32) {                                          // producer
+        LDT_REQUIRE(a->resid && a->ldr % 4 == 0 && ldt_aligned16(a->resid), LDT_EALIGN, "gemm_lnfold: resid missing/misaligned");
+        LDT_REQUIRE(!a->gate || (a->rows_per_sample > 0 && ldt_aligned16(a->gate) && a->gate_sample_stride % 4 == 0 && a->gate_step_stride % 4 == 0),
+                    LDT_EARG, "gemm_lnfold: gate needs rows_per_sample>0 and 16-byte aligned strides");
+        LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm_lnfold: bias must be 16-byte aligned");
+        LDT_REQUIRE(a->xs && a->ln_scale && a->stats_out && a->ldxs % 4 == 0 && a->ldxs >= a->N && ldt_aligned16(a->xs) &&
+                    ldt_aligned16(a->ln_scale) && a->ln_step_stride % 4 == 0 && ldt_aligned16(a->stats_out), LDT_EARG,
+                    "gemm_lnfold: producer needs xs / ln_scale / stats_out (16-byte aligned)");
+        return launch_256<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
+    }
+    LDT_REQUIRE(epi == EPI_BF16 || epi == EPI_GELU_BF16, LDT_EARG, "gemm_lnfold: epilogue %d has no folded form", epi);
+    LDT_REQUIRE(a->stats_in && a->fold_S && a->fold_C && a->stats_parts >= 1 && a->stats_parts <= 4 && a->stats_parts * 256 == a->K &&
+                ldt_aligned16(a->stats_in) && ldt_aligned16(a->fold_S) && ldt_aligned16(a->fold_C) && a->fold_step_stride % 4 == 0, LDT_EARG,
+                "gemm_lnfold: consumer needs stats_in[K/256 <= 4][M][2], fold_S, fold_C (16-byte aligned); K=%d parts=%d", a->K, a->stats_parts);
+    return epi == EPI_BF16 ? launch_256<EPI_BF16, FOLD_CONSUMER>(a, stream) : launch_256<EPI_GELU_BF16, FOLD_CONSUMER>(a, stream);
 }
 
 // LDT_GEMM_FORCE=128|256 pins the variant (A/B runs); default: 256^2 when it fills at least half the CUs.

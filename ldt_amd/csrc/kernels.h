@@ -19,6 +19,13 @@ struct GemmArgs {
     int rows_per_sample;
     const int* step_ptr; long gate_step_stride;   // gate += *step_ptr * gate_step_stride (device-side step counter)
     int M, N, K;
+    // ---- LayerNorm folding (256-tile kernel, interior tiles only; gemm_bf16.hip "LN folding") ----
+    // producer (EPI_RESID_F32): second output xs[m][n] = bf16(out[m][n] * (1 + ln_scale[n])) and per-row partial
+    // (sum, sum of squares) of out over each 256-column tile: stats_out[(n/256)][M][2]
+    bf16_t* xs; long ldxs; const float* ln_scale; long ln_step_stride; float* stats_out;
+    // consumer (EPI_BF16 / EPI_GELU_BF16): X is the producer's xs; out = epi( rstd*acc - rstd*mean*fold_S[n] + fold_C[n] )
+    // with (mean, rstd) of each row from stats_in[stats_parts][M][2] over the K input channels
+    const float* stats_in; int stats_parts; const float* fold_S; const float* fold_C; long fold_step_stride;
 };
 
 struct LnArgs {
@@ -59,6 +66,7 @@ struct SgemmArgs {
 };
 
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
+int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);
 int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s);

@@ -152,7 +152,8 @@ class DiffusionVPSDE:
             cond_ref, keep = None, None
             if condition is None and label is None:
                 _, mod = model.time_table(ts.to(dev))                                 # AdaLN rows for every step ...
-                plan = model.plan(B, T, mod, model.n_mod, 0)                          # ... shared by the batch
+                fold = model.fold_table(mod) if model.can_fold(B, T) else None        # (+ the LN-folding S / C rows)
+                plan = model.plan(B, T, mod, model.n_mod, 0, fold=fold)               # ... shared by the batch
             else:                                                                     # per-sample rows, rebuilt every step
                 extra, kv, S = model.condition_embedding(label, condition)
                 temb = model.time_embedding(ts.to(dev))

@@ -14,6 +14,7 @@ Host-side responsibilities kept in Python:
     for all N steps in one batched call instead of 25 GEMVs per step (SURVEY hard part 3).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -188,11 +189,13 @@ class Score(nn.Module):
                 "X": torch.empty((M, D), dtype=torch.float32, device=dev),
                 "Hb": torch.empty((M, D), **bf), "QKV": torch.empty((M, 3 * D), **bf),
                 "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
+                "stats": torch.empty((max(D // 256, 1), M, 2), dtype=torch.float32, device=dev),
             }}
         return self._ws[k]
 
-    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0):
-        """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows}."""
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None):
+        """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows};
+        fold: the `fold_table(mod)` of a batch-shared `mod` (enables the LN-folded GEMM epilogues)."""
         P, W = self.packed(), self._workspace(B, T)
         p = ScorePlan()
         p.hidden, p.heads, p.blocks = self.hidden_size, self.num_heads, self.num_blocks
@@ -212,7 +215,11 @@ class Score(nn.Module):
             for l, kv in kv_cond.items():
                 wq, bq, _, _ = self._cross_panels(l)
                 p.w_q[l], p.b_q[l], p.kv_cond[l] = wq.data_ptr(), bq.data_ptr(), kv.data_ptr()
-        p._keep = (P, W, mod, kv_cond)   # keep the buffers alive as long as the plan
+        if fold is not None:
+            if mod_sample_stride != 0:
+                raise ValueError("LN folding needs batch-shared modulation (mod_sample_stride == 0)")
+            p.fold, p.fold_step_stride, p.stats = fold.data_ptr(), fold.stride(0), W["stats"].data_ptr()
+        p._keep = (P, W, mod, kv_cond, fold)   # keep the buffers alive as long as the plan
         return p
 
     # ------------------------------------------------------------------ AdaLN tables
@@ -242,6 +249,36 @@ class Score(nn.Module):
         lin = self.ln_out.adaLN[1]
         ops.sgemm(c, lin.weight, lin.bias, act_in=ACT_SILU, out=mod[:, self.num_blocks * 6 * D:])
         return c, mod
+
+    def can_fold(self, B, T):
+        """LN folding pays when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs fill the chip
+        (>= 128 tiles).  LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
+        mode = int(os.environ.get("LDT_LN_FOLD", "1"))
+        D, M = self.hidden_size, B * T
+        if mode == 0 or self.unet or D % 256 or D > 1024 or M % 256 or self.Transformer[0].mlp.out.in_channels % 256:
+            return False
+        return mode == 2 or (M // 256) * (D // 256) >= 128
+
+    def fold_table(self, mod):
+        """Per-step S / C vectors of the LN-folded projections (include/ldt_hip.h, ldt_gemm_resid_lnstats), fp32
+        [n, blocks * (6D + 2F)], block l = [S_qkv 3D | C_qkv 3D | S_up F | C_up F]:
+            S[n] = sum_k (1 + scale[k]) W[n][k],   C[n] = sum_k shift[k] W[n][k] + b[n]
+        with (shift, scale) the rows of `mod` feeding that block's LayerNorm (layers.py:214,218-219) and W the bf16
+        panel the GEMM multiplies by (widened to fp32), so the mean term cancels against what the MFMAs accumulate."""
+        P = self.packed()
+        D, F = self.hidden_size, self.Transformer[0].mlp.out.in_channels
+        n = mod.shape[0]
+        fb = 6 * D + 2 * F
+        fold = torch.empty((n, self.num_blocks * fb), dtype=torch.float32, device=mod.device)
+        for l in range(self.num_blocks):
+            m0, f0 = l * 6 * D, l * fb
+            for (w, b, sh, sc, off) in ((P["w_qkv"][l], P["b_qkv"][l], m0, m0 + D, f0),
+                                        (P["w_up"][l], P["b_up"][l], m0 + 3 * D, m0 + 4 * D, f0 + 6 * D)):
+                wf = w.float()
+                N = wf.shape[0]
+                ops.sgemm(mod[:, sc:sc + D], wf, wf.sum(1), out=fold[:, off:off + N])               # S
+                ops.sgemm(mod[:, sh:sh + D], wf, b, out=fold[:, off + N:off + 2 * N])               # C
+        return fold
 
     # ------------------------------------------------------------------ reference API
     def label_embedding(self, label):

@@ -69,6 +69,55 @@ def test_gemm_all_epilogues(M, N, K):
     assert rel_mse(rd.cpu(), resid.double() + ref) < 1e-9
 
 
+@pytest.mark.parametrize("M,D,N2,gelu", [(512, 1024, 768, False), (256, 512, 2048, True), (768, 256, 256, False)])
+def test_gemm_lnfold_pair(M, D, N2, gelu):
+    """LN folding (include/ldt_hip.h): residual GEMM that also emits xs = x(1+scale) + row statistics, then the
+    projection that applies the LayerNorm algebraically in its epilogue — against LayerNorm -> modulate -> Linear in
+    fp64 on the same bf16 weights.  The row mean is deliberately NOT small (|mean| ~ 0.5 std)."""
+    from ldt_amd._lib import EPI_BF16, EPI_GELU_BF16
+    g = torch.Generator().manual_seed(M + D + N2)
+    K1 = 512
+    a = bf(torch.randn(M, K1, generator=g)); wo = bf(torch.randn(D, K1, generator=g) / K1 ** 0.5); bo = torch.randn(D, generator=g)
+    x0 = torch.randn(M, D, generator=g) * 1.5 + 0.6
+    rps = 128
+    gate = torch.randn(M // rps, D, generator=g)
+    sc = 0.3 * torch.randn(D, generator=g); sh = 0.3 * torch.randn(D, generator=g)
+    w2 = bf(torch.randn(N2, D, generator=g) / D ** 0.5); b2 = torch.randn(N2, generator=g)
+    # ---- producer
+    xd = dev(x0.clone())
+    xs, stats = ops.gemm_resid_lnstats(dev(a, torch.bfloat16), dev(wo, torch.bfloat16), dev(bo), xd, dev(sc), gate=dev(gate),
+                                       gate_sample_stride=D, rows_per_sample=rps)
+    xref = x0.double() + gate.double().repeat_interleave(rps, 0) * (a.double() @ wo.double().T + bo.double())
+    assert rel_mse(xd.cpu(), xref) < 1e-9
+    assert rel_mse(xs.float().cpu(), xref * (1 + sc.double())) < 1e-5
+    st = stats.cpu().double()
+    tiles = xd.cpu().double().view(M, D // 256, 256)
+    assert rel_mse(st[..., 0], tiles.sum(-1).T) < 1e-10 and rel_mse(st[..., 1], (tiles ** 2).sum(-1).T) < 1e-10
+    again = ops.gemm_resid_lnstats(dev(a, torch.bfloat16), dev(wo, torch.bfloat16), dev(bo), dev(x0.clone()), dev(sc), gate=dev(gate),
+                                   gate_sample_stride=D, rows_per_sample=rps)
+    assert torch.equal(again[0], xs) and torch.equal(again[1], stats)          # fixed summation order: reproducible
+    # ---- consumer
+    S = (w2.double() * (1 + sc.double())).sum(1).float(); C = (w2.double() @ sh.double() + b2.double()).float()
+    y = ops.gemm_lnfold(xs, dev(w2, torch.bfloat16), stats, dev(S), dev(C), EPI_GELU_BF16 if gelu else EPI_BF16)
+    xn = xd.cpu().double()
+    h = (xn - xn.mean(1, keepdim=True)) / torch.sqrt(xn.var(1, unbiased=False, keepdim=True) + 1e-6) * (1 + sc.double()) + sh.double()
+    ref = h @ w2.double().T + b2.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    # unfused path on the same inputs for comparison: LN kernel -> bf16 h -> GEMM
+    hb = ops.layernorm_modulate(xd, shift=dev(sh), scale=dev(sc), rows_per_sample=M)
+    y0 = ops.gemm_bf16(hb, dev(w2, torch.bfloat16), dev(b2), EPI_GELU_BF16 if gelu else EPI_BF16)
+    e_fold, e_ln = rel_mse(y.float().cpu(), ref), rel_mse(y0.float().cpu(), ref)
+    assert e_fold < 3e-5 and e_fold < 4 * e_ln + 1e-6, (e_fold, e_ln)
+
+
+def test_gemm_lnfold_rejects_bad_shapes():
+    from ldt_amd._lib import LdtHipError
+    x = torch.zeros(256, 512, dtype=torch.bfloat16, device="cuda"); w = torch.zeros(300, 512, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(LdtHipError):
+        ops.gemm_resid_lnstats(x, w, None, torch.zeros(256, 300, device="cuda"), torch.zeros(300, device="cuda"))
+
+
 def test_gemm_identity_asymmetric():
     """A = I with an ASYMMETRIC B catches a transposed C write (guide §3)."""
     from ldt_amd._lib import EPI_F32

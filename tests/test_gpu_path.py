@@ -255,6 +255,43 @@ def test_midsize_score_vs_oracle():
     assert rel_mse(out.cpu(), ref) < TOL_PARAMS
 
 
+def test_lnfold_sampler_vs_oracle_and_unfolded(monkeypatch):
+    """The fused sampling loop with LN folding forced on (hidden 256, 3 blocks, M = 8*32 = 256 rows) against the CPU
+    oracle's free-running trajectory, and against the same loop with the LayerNorm kernels (LDT_LN_FOLD=0)."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    N = 25                                                    # (N <= 20 makes beta_max = 20/N >= 1: 1/sqrt(1-beta) blows up, in the reference too)
+    cfg = ldt_amd.airplane_config(latent_tokens=32, sample_N=N, **{
+        "score.hidden_size": 256, "score.num_heads": 4, "score.num_blocks": 3, "score.t_dim": 128,
+        "compressor.max_outputs": 256, "compressor.outsize": 256, "data.tr_max_sample_points": 256})
+    torch.manual_seed(11)
+    score = ldt_amd.Score(cfg.score)
+    sd = {k: v.detach().clone() for k, v in score.state_dict().items()}
+    comp = ldt_amd.Compressor(cfg.compressor)
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    B, T, z = 8, cfg.score.z_scale, cfg.score.z_dim
+    x0, noises = O.draw_noises(77, B, T, z, N)
+    kw = dict(score_fn=tr.score_fn, num_samples=B, N=N, predictor="ancestral", corrector=None, corrector_steps=1, shape=(T, z),
+              time_eps=cfg.sde.sample_time_eps, probability_flow=False, denoise=True, snr=0.01, device="cuda:0", x0=x0,
+              noise=torch.stack(noises))
+    monkeypatch.setenv("LDT_LN_FOLD", "2")
+    assert tr.model.can_fold(B, T)
+    folded = tr.SDE.sample_discrete(**kw, use_graph=0)
+    folded_g = tr.SDE.sample_discrete(**kw, use_graph=1)
+    assert torch.equal(folded, folded_g)
+    monkeypatch.setenv("LDT_LN_FOLD", "0")
+    assert not tr.model.can_fold(B, T)
+    plain = tr.SDE.sample_discrete(**kw, use_graph=0)
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd, cfg.score, x, t))
+    ref = O.sample_discrete(sde, fn, x0, noises, N, predictor=cfg.sde.predictor, time_eps=cfg.sde.sample_time_eps,
+                            denoise=cfg.sde.denoise, probability_flow=cfg.sde.probability_flow)
+    e_f, e_p = rel_mse(folded.cpu(), ref), rel_mse(plain.cpu(), ref)
+    assert e_f < TOL_LATENT and e_p < TOL_LATENT, (e_f, e_p)
+    assert not torch.equal(folded, plain)                     # the two paths really are different code
+    assert rel_mse(folded.cpu(), plain.cpu()) < TOL_LATENT
+
+
 def test_ema_swap_repacks_weights(env):
     """EMA swap (tools/utils.py:80-101) re-points parameters; the packed bf16 panels must follow."""
     ldt, cfg = env["ldt"], env["cfg"]
