@@ -43,35 +43,41 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU (nn.GELU() default; model/layers.py:111-113 via tools/utils.py:107-108).
 // gelu_erf: libm erff (fp32-accurate; used by the fp32 SGEMM path).
-// gelu_erf_fast: GEMM epilogue form whose output is rounded to bf16 anyway — erf by Abramowitz & Stegun 7.1.26
-// (|abs err| <= 1.5e-7, i.e. ~2^-13 of a bf16 ulp at |x|~1), branch-free: 1 rcp + 1 exp + 8 FMA instead of erff.
+// gelu_erf_fast / gelu_erf_fast2: GEMM-epilogue forms whose output is rounded to bf16 anyway.  The lower normal tail is
+// written as a power of two of a polynomial,
+//     Phi(-z) = 1/2 * 2^(-z (c1 + c2 z + c3 z^2 + c4 z^3 + c5 z^4)),   z = |x|,
+// (-log2(2 Phi(-z)) is smooth and nearly quadratic; coefficients: weighted minimax fit of the GELU error over z in
+// [0, 13]; the polynomial stays >= c1 for every z >= 0, so large |x| saturates to 2^-inf = 0 without a clamp), then
+//     x Phi(x) = x/2 + |x| (1/2 - Phi(-|x|)) :  ONE transcendental (v_exp_f32), no reciprocal, no compare/select.
+// Evaluated in fp32: |gelu_fast(x) - gelu(x)| <= 8.7e-7 for every finite x (the accuracy of the A&S 7.1.26 erfc form it
+// replaces, which cost a reciprocal and an exponential per element): 12 VALU per PAIR instead of 19.
+#define LDT_GELU_C1 1.1510004997253418f
+#define LDT_GELU_C2 0.45959582924842834f
+#define LDT_GELU_C3 0.052146632224321365f
+#define LDT_GELU_C4 (-0.007198718376457691f)
+#define LDT_GELU_C5 0.00048810214502736926f
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(|x|/sqrt2)
-    const float phi = 0.5f * erfc_z;                                                    // Phi(-|x|)
-    return x * (x >= 0.f ? 1.0f - phi : phi);
+    const float z = fabsf(x);
+    float p = fmaf(LDT_GELU_C5, z, LDT_GELU_C4);
+    p = fmaf(p, z, LDT_GELU_C3);
+    p = fmaf(p, z, LDT_GELU_C2);
+    p = fmaf(p, z, LDT_GELU_C1);
+    const float e = __builtin_amdgcn_exp2f(-(p * z));            // 2 Phi(-z)
+    const float r = fmaf(e, -0.5f, 0.5f);                        // 1/2 - Phi(-z)
+    return fmaf(z, r, x * 0.5f);
 }
-// two-lane form of gelu_erf_fast for VALU-bound epilogues: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32
+// two-lane form: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-    const f32x2 z = ax * 0.70710678118654752440f;
-    const f32x2 den = z * 0.3275911f + 1.0f;
-    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-    f32x2 p = t * 1.061405429f + (-1.453152027f);
-    p = p * t + 1.421413741f;
-    p = p * t + (-0.284496736f);
-    p = p * t + 0.254829592f;
-    const f32x2 e = z * z * (-1.4426950408889634f);
-    const f32x2 ex = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-    // x Phi(x) = x/2 + |x| (1/2 - Phi(-|x|)),  Phi(-|x|) = erfc(z)/2 = p t ex / 2 : no compare/select
-    const f32x2 r = (p * t) * ex * (-0.5f) + 0.5f;
-    return x * 0.5f + ax * r;
+    const f32x2 z = {fabsf(x[0]), fabsf(x[1])};
+    f32x2 p = z * LDT_GELU_C5 + LDT_GELU_C4;
+    p = p * z + LDT_GELU_C3;
+    p = p * z + LDT_GELU_C2;
+    p = p * z + LDT_GELU_C1;
+    const f32x2 q = p * z;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const f32x2 r = e * (-0.5f) + 0.5f;
+    return x * 0.5f + z * r;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

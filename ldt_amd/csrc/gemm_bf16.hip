@@ -22,6 +22,8 @@
 //   EPI_RESID_F32  out fp32  = resid + gate[s,n] * (acc + bias)           (x + gate*(...), layers.py:218-219; gate may be null)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 #define BK 64
@@ -207,9 +209,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
 //   * Epilogue: accumulators -> per-wave 4 KiB LDS staging area (beside the ring, 160 KiB LDS in total) -> 16-B
 //     per lane accesses over whole output rows (the raw fragment layout is store-issue bound, guide T21); stores
 //     are not waited for, they drain under the next tile's main loop.
-#ifndef V2_NEXT_IN_L
-#define V2_NEXT_IN_L 1
-#endif
 #define V2_STAGE_BYTES 32768
 #define V2_OPER_BYTES 16384
 #define V2_RING_BYTES (4 * V2_STAGE_BYTES)
@@ -299,15 +298,36 @@ __device__ __forceinline__ float row16_sum(float v) {
 //   FOLD_CONSUMER (EPI_BF16 / EPI_GELU_BF16): X = xs; the tile's 256 rows x stats_parts partials are fetched by one
 //     LDS-DMA piece per wave during the main loop (into the unused tail of the bf16 staging areas), r / -r mu are
 //     formed per lane at the start of the epilogue and y = r acc + (-r mu S + C) replaces acc + bias.
-//   S, C are batch-invariant per-step tables built by the host in fp32 from the same bf16 W the MFMAs read.
+//   S, C are batch-invariant per-step tables built by the host in fp32 from the same bf16 W the MFMAs read; they are
+//   step-indexed, hence cold in every cache at every step: the tile's two 1 KiB slices ride the same mid-loop DMA slot
+//   (four half-wave pieces) so that the epilogue opens on LDS reads instead of an HBM round trip.  For the same reason
+//   the residual epilogue's step-indexed gate / ln_scale vectors of a workgroup's first tile are loaded before the
+//   main loop and kept in 8 VGPRs.
 enum { FOLD_NONE = 0, FOLD_PRODUCER = 1, FOLD_CONSUMER = 2 };
 #define V2_STATS_OFF 2304            /* bf16 staging uses 16 rows x 144 B of each wave's 4 KiB */
+#define V2_SC_OFF (V2_STATS_OFF + 1024)   /* 512 B: a 128-column slice of fold_S (waves 0, 1) or fold_C (waves 2, 3) */
+
+// FOLD_CONSUMER, once per tile and off the epilogue's critical path: thread R < 256 adds row R's partial (sum, sumsq)
+// pairs (piece part*2 + (R >> 7) sits in that wave's staging tail) and overwrites the part-0 slot with (rstd, -mean*rstd).
+__device__ __forceinline__ void v2_fold_finalize(char* stage_base, int R, int parts, int K) {
+    char* slot = stage_base + (R >> 7) * 4096 + V2_STATS_OFF + (R & 127) * 8;
+    float s1 = 0.f, s2 = 0.f;
+    for (int pp = 0; pp < parts; ++pp) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(slot + pp * 2 * 4096);
+        s1 += t[0]; s2 += t[1];
+    }
+    const float invk = 1.0f / (float)K;
+    const float mean = s1 * invk;
+    const float var = fmaxf(s2 * invk - mean * mean, 0.f);
+    const float r = rsqrtf(var + 1e-6f);
+    *reinterpret_cast<f32x2*>(slot) = (f32x2){r, -mean * r};
+}
 
 // interior tiles: per-wave LDS staging (16 output rows per pass) -> 16 B per lane over whole rows
 template <int EPI, int FOLD>
 __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
                                                    int lane, int lrow, int lchk, const float* gate, char* reg, char* stage_base,
-                                                   const float* fold_S, const float* fold_C, const float* ln_scale) {
+                                                   const float* ln_scale, bool have_pre, f32x4 g4_pre, f32x4 sc4_pre) {
     const int mb = m0 + grp * 128, nb = n0 + wn * 64;
     f32x4 bias4[4];
 #pragma unroll
@@ -318,24 +338,17 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
         f32x4 s4[4];
         float rr[8], nm[8];
         if (FOLD == FOLD_CONSUMER) {
-            const float invk = 1.0f / (float)a.K;
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int R = grp * 128 + mi * 16 + lrow;         // row inside the tile; piece q = part*2 + (R >> 7) sits in wave q's area
-                float s1 = 0.f, s2 = 0.f;
-                for (int pp = 0; pp < a.stats_parts; ++pp) {
-                    const f32x2 t = *reinterpret_cast<const f32x2*>(stage_base + (pp * 2 + (R >> 7)) * 4096 + V2_STATS_OFF + (R & 127) * 8);
-                    s1 += t[0]; s2 += t[1];
-                }
-                const float mean = s1 * invk;
-                const float var = fmaxf(s2 * invk - mean * mean, 0.f);
-                rr[mi] = rsqrtf(var + 1e-6f);
-                nm[mi] = -mean * rr[mi];
+            for (int mi = 0; mi < 8; ++mi) {                      // (rstd, -mean*rstd) of the lane's rows, finalised mid-loop (v2_fold_finalize)
+                const int R = grp * 128 + mi * 16 + lrow;
+                const f32x2 t = *reinterpret_cast<const f32x2*>(stage_base + (R >> 7) * 4096 + V2_STATS_OFF + (R & 127) * 8);
+                rr[mi] = t[0]; nm[mi] = t[1];
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                s4[ni] = *reinterpret_cast<const f32x4*>(fold_S + nb + ni * 16 + lchk * 4);
-                bias4[ni] = *reinterpret_cast<const f32x4*>(fold_C + nb + ni * 16 + lchk * 4);
+                const int c = wn * 64 + ni * 16 + lchk * 4;       // S | C slices of this tile: DMA'd into waves 0..3's areas
+                s4[ni] = *reinterpret_cast<const f32x4*>(stage_base + (c >> 7) * 4096 + V2_SC_OFF + (c & 127) * 4);
+                bias4[ni] = *reinterpret_cast<const f32x4*>(stage_base + (2 + (c >> 7)) * 4096 + V2_SC_OFF + (c & 127) * 4);
             }
         }
 #pragma unroll
@@ -343,7 +356,11 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[ni][mi];
+#ifdef V2_DBG_FOLD_NOMATH
+                if (false) {
+#else
                 if (FOLD == FOLD_CONSUMER) {
+#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * rr[mi] + (nm[mi] * s4[ni][r] + bias4[ni][r]);
                 } else {
@@ -382,11 +399,11 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
         f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
         const bool has_gate = (EPI == EPI_RESID_F32) && gate;
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
-        if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
+        if (shared_gate) g4 = have_pre ? g4_pre : *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
         float rs1[8], rs2[8];                                     // FOLD_PRODUCER: lanes with (lane & 15) < 4 keep row (lane&15)*4 + (lane>>4) of pass mi
         if (FOLD == FOLD_PRODUCER) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ln_scale + nb + ch * 4);
+            const f32x4 t = have_pre ? sc4_pre : *reinterpret_cast<const f32x4*>(ln_scale + nb + ch * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc4[r] = 1.0f + t[r];
         }
@@ -469,9 +486,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     const int my_tiles = (c_hi - c_lo - j + wpx - 1) / wpx > 0 ? (c_hi - c_lo - j + wpx - 1) / wpx : 0;
     if (my_tiles == 0) return;                                           // whole workgroup, before any barrier
 
+    // Tile order: GROUPED — `gm` row panels are swept column by column before the next `gm` rows, so the tiles an XCD's
+    // 32 workgroups hold at any time form a (gm rows x 32/gm columns) block: gm X panels + 32/gm W panels are live in
+    // its 4 MiB L2 instead of 2 + 16 (row-major order at 16 column tiles).
+    const int tiles_m = (a.M + 255) / 256, gm = a.group_m;
     auto tile_of = [&](int it, int& m0, int& n0) {
         const int id = c_lo + j + it * wpx;
-        m0 = (id / tiles_n) * 256; n0 = (id % tiles_n) * 256;
+        if (gm <= 1) { m0 = (id / tiles_n) * 256; n0 = (id % tiles_n) * 256; return; }
+        const int per = gm * tiles_n, g = id / per, r = id - g * per;
+        const int rows = min(gm, tiles_m - g * gm);
+        m0 = (g * gm + r % rows) * 256; n0 = (r / rows) * 256;
     };
     // Advance a stream by one sub-tile (called right after the MFMAs of a phase are issued): the common path is two
     // pointer bumps.  At the end of this workgroup's stream it parks (inc = 0): later batches re-read the last
@@ -500,6 +524,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
         v2_stream_seek(sx, a.X, a.ldx, m0, a.M, 0, wave, lane);
         v2_stream_seek(sw, a.W, a.ldw, n0, a.N, 0, wave, lane);
     }
+    // step-indexed (cache-cold) epilogue vectors of the FIRST tile, fetched ahead of everything else
+    const float* gate = a.gate;
+    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
+    const float* ln_scale = (FOLD == FOLD_PRODUCER) ? a.ln_scale + (long)step * a.ln_step_stride : nullptr;
+    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
+    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
+    f32x4 g4_pre = {1.f, 1.f, 1.f, 1.f}, sc4_pre = {0.f, 0.f, 0.f, 0.f};
+    const bool pre_ok = (EPI == EPI_RESID_F32) && gate && a.gate_sample_stride == 0;
+    if (EPI == EPI_RESID_F32) {
+        int m0, n0;
+        tile_of(0, m0, n0);
+        if (n0 + 256 <= a.N) {
+            if (pre_ok) g4_pre = *reinterpret_cast<const f32x4*>(gate + n0 + wn * 64 + (lane & 15) * 4);
+            if (FOLD == FOLD_PRODUCER) sc4_pre = *reinterpret_cast<const f32x4*>(ln_scale + n0 + wn * 64 + (lane & 15) * 4);
+        }
+    }
     int gx = 0, gw = 0;                                                  // stream positions of the next X / W batch
 #define ISSUE_X() do { v2_stream_issue(sx, smem2 + (gx & 3) * V2_STAGE_BYTES, wave); ++gx; } while (0)
 #define ISSUE_W() do { v2_stream_issue(sw, smem2 + (gw & 3) * V2_STAGE_BYTES + V2_OPER_BYTES, wave); ++gw; } while (0)
@@ -507,6 +548,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx);   // X0 W0 X1 W1 X2
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     // sub-tile 0 landed
     V2_BARRIER();
+    if (EPI == EPI_RESID_F32)                                            // (older than every DMA above: already retired)
+        asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
 
     // per-lane LDS read offsets inside a ring slot: row*64 + ((chunk ^ f(row)) << 4)
     int xoff[8], woff[4];
@@ -519,12 +562,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     // a smaller count only waits longer (FOLD_PRODUCER: 32 x + 32 xs + 1 stats stores exceed the 6-bit counter)
     constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
                              : (FOLD == FOLD_PRODUCER) ? 57 : 32;
-    const float* gate = a.gate;
-    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
-    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
-    const float* ln_scale = (FOLD == FOLD_PRODUCER) ? a.ln_scale + (long)step * a.ln_step_stride : nullptr;
-    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
-    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
     const bool aligned = (a.ldo % 8 == 0) && (EPI != EPI_RESID_F32 || a.ldr % 4 == 0) && (EPI != EPI_RELU_BF16 || !a.skip || a.lds_ % 4 == 0);
     char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
 
@@ -540,7 +577,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
             for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
 
-        for (int v = 0; v < nks; ++v, ++g) {
+        // One 32-deep sub-tile = two phases.  The load segment is the loop's critical resource (it is longer than the
+        // partner's 16-MFMA segment): three TAKEN skip-branches per sub-tile around rarely executed blocks cost 8-11 % of
+        // the whole GEMM (measured), while the not-taken tile-switch branch of next_x / next_w is free (a branch-free
+        // bump/seek form measured equal).  So the once-per-tile extras of FOLD_CONSUMER are separate instantiations of
+        // the body (ST_* flags) placed at fixed sub-tile positions, not runtime tests inside one loop body.
+        enum { ST_PLAIN = 0, ST_FIRST = 1 /* first wait allows for the previous epilogue's stores */, ST_CHECK_FIRST = 2 /* runtime v == 0 */,
+               ST_FOLD_DMA = 4 /* fetch this tile's row statistics + S | C slices */, ST_FOLD_FINAL = 8 /* (rstd, -mean rstd) per row */ };
+        int v = 0;
+        auto subtile = [&](auto flags_c) {
+            constexpr int FL = decltype(flags_c)::value;
             const char* st = smem2 + (g & 3) * V2_STAGE_BYTES;
             bf16x8 wf[4], xf[4];
             // ---------------- phase 0: W (4 n-tiles) + X (m-tiles 0..3); DMA: W of stream position g+2 ----------------
@@ -549,17 +595,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
             ISSUE_W();
-#if V2_NEXT_IN_L
             next_w(sw);
-#endif
-            if (FOLD == FOLD_CONSUMER && v == 2 && wave < 2 * a.stats_parts) {
-                // row statistics of this tile: piece q = wave = part*2 + half -> 128 rows x 8 B, into the tail of this wave's
-                // staging area.  Issued two sub-tiles into the tile (every wave is past the previous epilogue's reads: >= 8
-                // barriers), retired by the counted wait of sub-tile 3 and read only in the epilogue (K >= 256).
-                const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
+            if (FL & ST_FOLD_DMA) {
+                // Row statistics of this tile: piece q = wave = part*2 + half -> 128 rows x 8 B, into the tail of this wave's
+                // staging area; S | C: four half-wave pieces.  Issued two sub-tiles into the tile (every wave is past the
+                // previous epilogue's reads: >= 8 barriers), retired by the counted wait of sub-tile 3, read from sub-tile 6 on.
+                if (wave < 2 * a.stats_parts) {
+                    const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
+                }
+                if (wave < 4 && lane < 32) {
+                    const float* src = (wave < 2 ? fold_S : fold_C) + n0 + (wave & 1) * 128 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_SC_OFF), 16, 0, 0);
+                }
             }
+            if ((FL & ST_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -568,21 +620,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-#if !V2_NEXT_IN_L
-            __builtin_amdgcn_sched_barrier(0);
-            next_w(sw);                                                  // address work for the next W batch, under the MFMAs
-#endif
             V2_BARRIER();
             // ---------------- phase 1: X (m-tiles 4..7); DMA: X of stream position g+3; counted wait ----------------
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
             ISSUE_X();
-#if V2_NEXT_IN_L
             next_x(sx);
-#endif
             // position g+1 has landed once all but the 3 newest batches (+ a preceding epilogue's stores) retired
             // (an edge epilogue issues a data-dependent number of stores: fall back to the always-safe vmcnt(6))
-            if (v == 0 && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + EPI_VMEM) : "memory");
+            if (((FL & ST_FIRST) || ((FL & ST_CHECK_FIRST) && v == 0)) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + EPI_VMEM) : "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
@@ -592,17 +638,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-#if !V2_NEXT_IN_L
-            __builtin_amdgcn_sched_barrier(0);
-            next_x(sx);
-#endif
             V2_BARRIER();
+            ++g;
+        };
+#define SUBT(f) std::integral_constant<int, (f)>{}
+        if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 8 sub-tiles
+            subtile(SUBT(ST_FIRST)); subtile(SUBT(ST_PLAIN)); subtile(SUBT(ST_FOLD_DMA));
+            for (v = 3; v < 6; ++v) subtile(SUBT(ST_PLAIN));
+            subtile(SUBT(ST_FOLD_FINAL));
+            for (v = 7; v < nks; ++v) subtile(SUBT(ST_PLAIN));
+        } else {
+            for (v = 0; v < nks; ++v) subtile(SUBT(ST_CHECK_FIRST));
         }
+#undef SUBT
         if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
 
         prev_staged = (m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned;
         if (prev_staged || FOLD != FOLD_NONE)                            // FOLD: the launcher admits interior, aligned tiles only
-            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, fold_S, fold_C, ln_scale);
+            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
+                                          it == 0 && (pre_ok || FOLD == FOLD_PRODUCER), g4_pre, sc4_pre);
         else v2_epilogue_edge<EPI>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail batches before exit
@@ -610,8 +664,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #undef ISSUE_W
 }
 
+// rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
+static int g_group_m = -1;
+extern "C" void ldt_dbg_gemm_group_m(int gm) { g_group_m = gm; }
+
 template <int EPI, int FOLD = FOLD_NONE>
-static int launch_256(const GemmArgs* a, hipStream_t stream) {
+static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
+    if (g_group_m < 0) g_group_m = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : 1;
+    GemmArgs a_copy = *a_in;
+    a_copy.group_m = g_group_m;
+    const GemmArgs* a = &a_copy;
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI, FOLD>),

@@ -26,6 +26,7 @@ struct GemmArgs {
     // consumer (EPI_BF16 / EPI_GELU_BF16): X is the producer's xs; out = epi( rstd*acc - rstd*mean*fold_S[n] + fold_C[n] )
     // with (mean, rstd) of each row from stats_in[stats_parts][M][2] over the K input channels
     const float* stats_in; int stats_parts; const float* fold_S; const float* fold_C; long fold_step_stride;
+    int group_m;                        // 256-tile kernel: row panels per group of the tile order (set by the launcher)
 };
 
 struct LnArgs {
