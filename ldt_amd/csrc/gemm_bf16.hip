@@ -356,11 +356,7 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 f32x4 v = acc[ni][mi];
-#ifdef V2_DBG_FOLD_NOMATH
-                if (false) {
-#else
                 if (FOLD == FOLD_CONSUMER) {
-#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] * rr[mi] + (nm[mi] * s4[ni][r] + bias4[ni][r]);
                 } else {
@@ -500,21 +496,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     // Advance a stream by one sub-tile (called right after the MFMAs of a phase are issued): the common path is two
     // pointer bumps.  At the end of this workgroup's stream it parks (inc = 0): later batches re-read the last
     // sub-tile (valid memory), are counted by vmcnt like any other and are never consumed.
+    // (bump first, in place; the tile switch then overwrites the pointers: written this way the common path is straight-
+    //  line code with one NOT-taken branch — the "if (likely) { bump; return; }" form compiled to a taken branch plus two
+    //  64-bit register copies in every load segment)
     auto next_x = [&](V2Stream& st) {
+        st.p[0] += st.inc; st.p[1] += st.inc;
         const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
-        if (__builtin_expect(left != 0, 1)) { st.v = left; st.p[0] += st.inc; st.p[1] += st.inc; return; }
-        const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;        // once per tile
-        st.it = it;
-        if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.X, a.ldx, m0, a.M, 0, wave, lane); st.v = nks; }
-        else { st.v = 0x40000000; st.inc = 0; }
+        st.v = left;
+        if (__builtin_expect(left == 0, 0)) {                            // once per tile
+            const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
+            st.it = it;
+            if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.X, a.ldx, m0, a.M, 0, wave, lane); st.v = nks; }
+            else { st.p[0] -= st.inc; st.p[1] -= st.inc; st.v = 0x40000000; st.inc = 0; }
+        }
     };
     auto next_w = [&](V2Stream& st) {
+        st.p[0] += st.inc; st.p[1] += st.inc;
         const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
-        if (__builtin_expect(left != 0, 1)) { st.v = left; st.p[0] += st.inc; st.p[1] += st.inc; return; }
-        const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
-        st.it = it;
-        if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.W, a.ldw, n0, a.N, 0, wave, lane); st.v = nks; }
-        else { st.v = 0x40000000; st.inc = 0; }
+        st.v = left;
+        if (__builtin_expect(left == 0, 0)) {
+            const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
+            st.it = it;
+            if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.W, a.ldw, n0, a.N, 0, wave, lane); st.v = nks; }
+            else { st.p[0] -= st.inc; st.p[1] -= st.inc; st.v = 0x40000000; st.inc = 0; }
+        }
     };
 
     V2Stream sx{{nullptr, nullptr}, 0, nks, 32}, sw{{nullptr, nullptr}, 0, nks, 32};
