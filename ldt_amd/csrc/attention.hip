@@ -19,82 +19,120 @@
 // next MFMA's operand", k order 16s + 8(j>>2) + 4h + (j&3)).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// One 64-key tile of the online softmax + P·V for a wave (32 query rows, one per lane & 31; keys split over the
-// two half-waves).  VALU-lean: packed fp32 FMA/ADD/MUL (two scores per instruction), max3 row maxima, no masking
-// code on full tiles.  sacc = S^T accumulators of the two 32-key sub-tiles; Vt = row-major swizzled V tile.
+// Per-lane LDS offsets of the operand reads inside a K/V tile (the XOR swizzles depend on the lane only: 32- and 16-row
+// steps leave them unchanged), so every read below is `tile base + constant + one of these`.
 template <int DH>
-__device__ __forceinline__ void attn_tile_softmax_pv(f32x16 (&sacc)[2], f32x16 (&oacc)[DH / 32], float& m_run, float& l_run,
-                                                     const char* Vt, int kv0, int Nk, int hh, float c,
-                                                     int v_row_off, int v_chunk, int v_byte) {
-    constexpr int ROWB = DH * 2, ND = DH / 32, KT = 64;
-    auto swzV = [](int row) { return (DH == 64) ? (((row >> 1) & 1) << 2) : 0; };
-    if (kv0 + KT > Nk) {                                     // ragged last tile: mask keys >= Nk
+struct AttnLaneOffs {
+    int k0;                  // K row (lane & 31) of a 32-key block, 16-B chunk `half` (k-step 0); k-step s is k0 ^ (s << 5):
+                             // row*ROWB and the chunk bits do not overlap, and the swizzle only permutes chunks
+    int v[DH / 32];          // V^T fragments by ds_read_b64_tr_b16: row v_row_off of a 16-key step (row + 8: + 8*ROWB), 32-d tile d
+    __device__ __forceinline__ void init(int lane) {
+        constexpr int ROWB = DH * 2;
+        const int r = lane & 31, hh = lane >> 5;
+        const int swk = (DH == 64) ? ((r >> 1) & 7) : ((r >> 2) & 3);
+        k0 = r * ROWB + ((hh ^ swk) << 4);
+        const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+        const int v_row_off = 4 * (tg >> 1) + tq;                // key inside the 16-key k-step: 4*half + q
+        const int v_chunk = (tg & 1) * 2 + (tp >> 1);            // 16-B chunk inside a 32-d tile
+        const int v_byte = (tp & 1) * 8;
+        const int swv = (DH == 64) ? (((v_row_off >> 1) & 1) << 2) : 0;   // unchanged by +8 rows
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int d = 0; d < DH / 32; ++d) v[d] = v_row_off * ROWB + (((d * 4 + v_chunk) ^ swv) << 4) + v_byte;
+    }
+};
+
+// One 64-key tile for a wave (32 query rows, one per lane & 31; the keys of a 32-key block split over the two
+// half-waves), processed as two 32-key blocks: S^T = K Q^T (4 or 2 MFMAs), online softmax, O^T += V^T P^T.
+//   * The running reference m_run is moved (and O, l rescaled) only when some row's block maximum exceeds it by more
+//     than 2^ATT_THR (guide T13 "defer-max"): P = 2^((s - m_run) c) then stays <= 2^ATT_THR, exact in fp32 sums and
+//     with bf16's full relative precision, and the result O / l is the same quotient.  After the first block the
+//     branch is rarely taken, which removes the per-block alpha / rescale work (16 v_pk_mul at Dh = 64).
+//   * VALU-lean: packed fp32 FMA/ADD (two scores per instruction), max3 row maxima, masking code only on ragged tiles.
+#define ATT_THR 6.0f
+template <int DH>
+__device__ __forceinline__ void attn_block(const char* Kt, const char* Vt, const int kt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
+                                           float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
+                                           const AttnLaneOffs<DH>& lo) {
+    constexpr int ROWB = DH * 2, ND = DH / 32, NS = DH / 16;
+    {
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + kt * 32 * ROWB + (lo.k0 ^ (s << 5)));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+        }
+        if (kv0 + kt * 32 + 32 > Nk) {                           // ragged block: mask keys >= Nk
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = kv0 + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                sacc[kt][i] = (key < Nk) ? sacc[kt][i] : -INFINITY;
+                sacc[i] = (key < Nk) ? sacc[i] : -INFINITY;
             }
-    }
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+        }
+        float mx = __builtin_fmaxf(sacc[0], sacc[1]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][i]), sacc[1][i]);   // -> v_max3_f32
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const f32x2 c2 = {c, c}, nmc2 = {-m_new * c, -m_new * c};
-    f32x2 ps2 = {0.f, 0.f};
-    bf16x8 pf[2][2];
+        for (int i = 2; i < 16; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[i]), sacc[i + 1]);   // -> v_max3_f32
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > ATT_THR) != 0) {   // wave-uniform; always on the first block (m_run = -inf)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+            m_run = m_new;
+            const f32x2 a2 = {alpha, alpha};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 o = {oacc[d][i], oacc[d][i + 1]};
+                    o *= a2;                                     // v_pk_mul_f32
+                    oacc[d][i] = o[0]; oacc[d][i + 1] = o[1];
+                }
+        }
+        const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
+        f32x2 ps2 = {0.f, 0.f};
+        bf16x8 pf[2];
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-            const f32x2 sv = {sacc[kt][i], sacc[kt][i + 1]};
-            const f32x2 e = sv * c2 + nmc2;                  // v_pk_fma_f32
+            const f32x2 sv = {sacc[i], sacc[i + 1]};
+            const f32x2 e = sv * c2 + nmc2;                      // v_pk_fma_f32
             f32x2 pv;
             pv[0] = __builtin_amdgcn_exp2f(e[0]);
             pv[1] = __builtin_amdgcn_exp2f(e[1]);
-            ps2 += pv;                                       // v_pk_add_f32
-            pf[kt][i >> 3][i & 7] = (bf16_t)pv[0];
-            pf[kt][i >> 3][(i & 7) + 1] = (bf16_t)pv[1];
+            ps2 += pv;                                           // v_pk_add_f32
+            pf[i >> 3][i & 7] = (bf16_t)pv[0];
+            pf[i >> 3][(i & 7) + 1] = (bf16_t)pv[1];
         }
-    l_run = l_run * alpha + (ps2[0] + ps2[1]);
-    m_run = m_new;
-    const f32x2 a2 = {alpha, alpha};
+        l_run += ps2[0] + ps2[1];
+        // O^T += V^T · P^T : V^T fragments by transposed LDS reads of the row-major V tile
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            f32x2 o = {oacc[d][i], oacc[d][i + 1]};
-            o *= a2;                                         // v_pk_mul_f32
-            oacc[d][i] = o[0]; oacc[d][i + 1] = o[1];
-        }
-    // O^T += V^T · P^T : V^T fragments by transposed LDS reads of the row-major V tile
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int kr = kt * 32 + 16 * s2 + v_row_off;
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
-                const int chn = d * 4 + v_chunk;
-                const char* p0 = Vt + kr * ROWB + ((chn ^ swzV(kr)) << 4) + v_byte;
-                const char* p1 = Vt + (kr + 8) * ROWB + ((chn ^ swzV(kr + 8)) << 4) + v_byte;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p1));
-                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], oacc[d], 0, 0, 0);
+                const char* base = Vt + (kt * 32 + 16 * s2) * ROWB;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + lo.v[d]));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 8 * ROWB + lo.v[d]));
+                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[d], 0, 0, 0);
             }
-        }
+    }
+}
+template <int DH>
+__device__ __forceinline__ void attn_tile(const char* Kt, const char* Vt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
+                                          float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
+                                          const AttnLaneOffs<DH>& lo) {
+    attn_block<DH>(Kt, Vt, 0, qf, oacc, m_run, l_run, kv0, Nk, hh, c, lo);
+    attn_block<DH>(Kt, Vt, 1, qf, oacc, m_run, l_run, kv0, Nk, hh, c, lo);
 }
 
 template <int DH, bool OPROJ = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                      // keys per LDS tile
     constexpr int ROWB = DH * 2;                // K / V row bytes
     constexpr int CH = ROWB / 16;               // 16-B chunks per row (8 or 4)
@@ -132,28 +170,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
 
-    // register staging of one K/V tile (issue early, write to LDS late: guide T14)
-    bf16x8 kreg[NL], vreg[NL];
-    auto tile_load = [&](int kv0) {
+    // register staging of one K/V tile (issue early, write to LDS late: guide T14).  Thread -> (row, chunk) pieces are
+    // fixed, so the global offsets and the swizzled LDS offsets are computed once; a tile's rows are then `uniform tile
+    // pointer + per-lane offset`.  Rows past Nk (ragged last tile) re-read row Nk-1: their scores are masked to -inf,
+    // P is exactly 0 and the (finite) V values they multiply do not matter.
+    bf16x8 sreg[NL];                                         // ONE staging set: K of the next tile, then its V (half the registers)
+    // piece l of a thread is 256/CH rows below piece 0 and the swizzles repeat with that period: one offset per operand
+    constexpr int RPP = 256 / CH;
+    const int prow = tid / CH, pch = tid % CH;
+    const int gk_off = prow * (int)a.ldk + pch * 8, gv_off = prow * (int)a.ldv + pch * 8;
+    const int sk_off = prow * ROWB + ((pch ^ swzK(prow)) << 4), sv_off = prow * ROWB + ((pch ^ swzV(prow)) << 4);
+    auto stage_load = [&](const bf16_t* base, long ld, int goff, int kv0) {
+        const bf16_t* T = base + (long)kv0 * ld;
+        if (kv0 + KT <= a.Nk) {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int idx = tid + l * 256, row = idx / CH, ch = idx % CH;
-            int krow = kv0 + row;
-            const bool valid = krow < a.Nk;
-            krow = valid ? krow : a.Nk - 1;
-            kreg[l] = *reinterpret_cast<const bf16x8*>(Kb + (long)krow * a.ldk + ch * 8);
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(Vb + (long)krow * a.ldv + ch * 8);
-            const bf16x8 zero = {};
-            vreg[l] = valid ? vv : zero;                    // masked keys must contribute exact zeros to P·V
+            for (int l = 0; l < NL; ++l) sreg[l] = *reinterpret_cast<const bf16x8*>(T + (long)l * RPP * ld + goff);
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int back = max(kv0 + l * RPP + prow - (a.Nk - 1), 0);   // rows past the end fall back to row Nk-1
+                sreg[l] = *reinterpret_cast<const bf16x8*>(T + ((long)l * RPP - back) * ld + goff);
+            }
         }
     };
-    auto tile_store = [&](char* Ks, char* Vs) {
+    auto stage_store = [&](char* dst, int soff) {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int idx = tid + l * 256, row = idx / CH, ch = idx % CH;
-            *reinterpret_cast<bf16x8*>(Ks + row * ROWB + ((ch ^ swzK(row)) << 4)) = kreg[l];
-            *reinterpret_cast<bf16x8*>(Vs + row * ROWB + ((ch ^ swzV(row)) << 4)) = vreg[l];
-        }
+        for (int l = 0; l < NL; ++l) *reinterpret_cast<bf16x8*>(dst + l * RPP * ROWB + soff) = sreg[l];
     };
 
     f32x16 oacc[ND];
@@ -163,44 +205,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float c = a.scale_log2e;
+    AttnLaneOffs<DH> lo;
+    lo.init(lane);
 
-    // per-lane pieces of the transposed V read: 16-lane group g supplies row (lane&15)>>2 of a 4-key x 16-d block
-    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
-    const int v_row_off = 4 * (tg >> 1) + tq;               // key inside the 16-key k-step: 4*half + q
-    const int v_chunk = (tg & 1) * 2 + (tp >> 1);           // 16-B chunk inside a 32-d tile
-    const int v_byte = (tp & 1) * 8;
-
-    tile_load(0);
-    tile_store(smem, smem + TILE);
+    stage_load(Kb, a.ldk, gk_off, 0); stage_store(smem, sk_off);
+    stage_load(Vb, a.ldv, gv_off, 0); stage_store(smem + TILE, sv_off);
     __syncthreads();
 
+    // Two tiles per trip so that the LDS buffer of a tile is a compile-time constant (every LDS address below is then
+    // `per-lane offset + immediate`).  The next tile's K is fetched under the first 32-key block and written to the other
+    // buffer (consumed an iteration ago) before the second block, under which its V is fetched.
     const int ntiles = (a.Nk + KT - 1) / KT;
-    for (int t = 0; t < ntiles; ++t) {
+    auto do_tile = [&](int t, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
         const int kv0 = t * KT;
-        const char* Ks = smem + (t & 1) * 2 * TILE;
-        const char* Vs = Ks + TILE;
-        if (t + 1 < ntiles) tile_load(kv0 + KT);            // in flight under the MFMAs below
-
-        // ---- S^T = K·Q^T for the two 32-key sub-tiles ----
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
-            const int row = kt * 32 + r;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * ROWB + (((2 * s + hh) ^ swzK(row)) << 4));
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
-            }
-        }
-        attn_tile_softmax_pv<DH>(sacc, oacc, m_run, l_run, Vs, kv0, a.Nk, hh, c, v_row_off, v_chunk, v_byte);
-        // ---- stage the prefetched tile into the other buffer (its previous tile was consumed an iteration ago) ----
-        if (t + 1 < ntiles) {
-            char* nK = smem + ((t + 1) & 1) * 2 * TILE;
-            tile_store(nK, nK + TILE);
-        }
+        const bool more = t + 1 < ntiles;
+        char* cur = smem + BUF * 2 * TILE;
+        char* nxt = smem + (BUF ^ 1) * 2 * TILE;
+        if (more) stage_load(Kb, a.ldk, gk_off, kv0 + KT);
+        attn_block<DH>(cur, cur + TILE, 0, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+        if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+        attn_block<DH>(cur, cur + TILE, 1, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+        if (more) stage_store(nxt + TILE, sv_off);
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        do_tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) do_tile(t + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- normalise, stage the wave's 32 x DH output through LDS (the K/V buffers are idle after the last barrier)
@@ -335,9 +366,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
                 const int row = row0 + (base + l) * RPL;
                 const int krow = row < a.Nk ? row : a.Nk - 1;
                 kreg[l] = *reinterpret_cast<const bf16x8*>(Kb + (long)krow * a.ldk + ch * 8);
-                const bf16x8 vv = *reinterpret_cast<const bf16x8*>(Vb + (long)krow * a.ldv + ch * 8);
-                const bf16x8 zero = {};
-                vreg[l] = (row < a.Nk) ? vv : zero;                     // masked keys contribute exact zeros to P·V
+                vreg[l] = *reinterpret_cast<const bf16x8*>(Vb + (long)krow * a.ldv + ch * 8);   // rows past Nk: P is exactly 0 there
             }
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
@@ -351,8 +380,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
     __syncthreads();
 
     const float c = a.scale_log2e;
-    const int tg = lane >> 4, ti = lane & 15, tq = ti >> 2, tp = ti & 3;
-    const int v_row_off = 4 * (tg >> 1) + tq, v_chunk = (tg & 1) * 2 + (tp >> 1), v_byte = (tp & 1) * 8;
+    AttnLaneOffs<DH> lo;
+    lo.init(lane);
     const int nqb = (a.Nq + 127) / 128;
     for (int qb = 0; qb < nqb; ++qb) {
         const int q0 = qb * 128 + wave * 32;
@@ -371,24 +400,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        for (int t = 0; t < ntl; ++t) {
-            const int kv0 = t * KT;
-            const char* Kt = Ks + t * TILE;
-            const char* Vt = Vs + t * TILE;
-            f32x16 sacc[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
-                const int row = kt * 32 + r;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kt + row * ROWB + (((2 * s + hh) ^ swzK(row)) << 4));
-                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
-                }
-            }
-            attn_tile_softmax_pv<DH>(sacc, oacc, m_run, l_run, Vt, kv0, a.Nk, hh, c, v_row_off, v_chunk, v_byte);
-        }
+        for (int t = 0; t < ntl; ++t)
+            attn_tile<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
         // ---- normalise, stage through the wave's private LDS rows (XOR-swizzled chunks), store whole rows ----
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;

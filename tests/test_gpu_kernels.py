@@ -174,6 +174,29 @@ def test_attention_softmax_spike():
     assert float((out.float().cpu() - ref).abs().max()) < 0.02
 
 
+@pytest.mark.parametrize("dh,step", [(64, 2.0), (64, 5.0), (32, 3.0)])
+def test_attention_softmax_staircase(dh, step):
+    """Row maxima that keep growing along the key axis: every 32-key block raises the maximum of every query row by
+    `step` (in log2 units), below and above the deferred-rescale threshold of the kernel (2^6), so both the "keep the
+    stale reference" and the "rescale" paths run many times in one row; full-tensor fp64 reference."""
+    B, H, N = 2, 2, 320
+    C = H * dh
+    g = torch.Generator().manual_seed(int(step * 10) + dh)
+    q = torch.randn(B, N, C, generator=g) * 0.1; k = torch.randn(B, N, C, generator=g) * 0.1; v = torch.randn(B, N, C, generator=g)
+    # channel 0 of every head carries the staircase: q = a, k_j = (j // 32) * step * ln2 * sqrt(dh) / a  ->  score_j = (j//32) * step (log2 units)
+    a = 4.0
+    stair = (torch.arange(N) // 32).float() * step * 0.6931471805599453 * dh ** 0.5 / a
+    for h in range(H):
+        q[:, :, h * dh] = a
+        k[:, :, h * dh] = stair
+    q, k, v = bf(q), bf(k), bf(v)
+    ref = ref_attention(q, k, v, H)
+    out = ops.attention_fwd(dev(q, torch.bfloat16).view(B * N, C), dev(k, torch.bfloat16).view(B * N, C),
+                            dev(v, torch.bfloat16).view(B * N, C), B, H, N, N, dh)
+    assert rel_mse(out.float().cpu(), ref) < 2e-5
+    assert float((out.float().cpu() - ref).abs().max()) < 0.05
+
+
 # ------------------------------------------------------------------------------------------- LN / modulate
 @pytest.mark.parametrize("M,C", [(64, 1024), (10, 128), (33, 64), (8, 256), (5, 96)])
 def test_layernorm_modulate(M, C):
