@@ -140,7 +140,7 @@ def roofline_pass(trainer, cfg, B, reps=3):
     abytes = 4.0 * M * D * 2                                               # read Q,K,V + write O in bf16
     gbs = abytes / (a["avg_ms"] * 1e-3) / 1e9
     attn = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("attn_fwd_kernel<64>"), "kernel": "attn_fwd_kernel<64>",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("attn_fwd_kernel<64, false>"), "kernel": "attn_fwd_kernel<64, false>",
             "bytes_per_launch": abytes, "avg_launch_ms": a["avg_ms"]}
     return roof, attn, kernels
 
