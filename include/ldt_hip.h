@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 6
+#define LDT_ABI_VERSION 7
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -226,6 +226,10 @@ typedef struct ldt_score_plan {
        non-NULL, mod_sample_stride == 0, no cross-attention, M % 256 == 0, hidden % 256 == 0 <= 1024, mlp_hidden % 256 == 0;
        otherwise the LayerNorm kernels run (the host passes fold only where whole 256x256 tiles fill the chip). */
     const float* fold; int64_t fold_step_stride; float* stats;
+    /* Cap on the persistent GEMM grids of this plan (0 = one workgroup per CU = 256).  Two sub-batches sampled on two
+       streams give each plan 128: their kernels then share the chip CU-wise and one stream's HBM-bound epilogues /
+       attention overlap the other's MFMA-bound main loops (ldt_amd/diffusion.py, `streams`). */
+    int32_t gemm_wgs; int32_t _pad1;
 } ldt_score_plan;
 
 /* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */

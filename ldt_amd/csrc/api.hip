@@ -249,7 +249,7 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     LAUNCH(LDT_PROF_OTHER, ldt_cast_pad_launch(x, p->z_dim, BFM(p->xin), p->z_pad, M, p->z_dim, p->z_pad, s));
     {
         GemmArgs g{BF(p->xin), p->z_pad, BF(p->w_in), p->z_pad, p->b_in, p->X, D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, p->z_pad};
-        LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &g, s));
+        g.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &g, s));
     }
     for (int l = 0; l < p->blocks; ++l) {                       // score.py:148-149, layers.py:212-219
         const float* m = p->mod + (long)l * 6 * D;              // shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
@@ -257,7 +257,7 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         if (fold && l > 0) {                                    // Hb = x (1 + scale_msa) and the row statistics came from block l-1's mlp.out
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, nullptr, p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, 3 * D, D,
                         nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl, fl + 3L * D, fstep};
-            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
@@ -267,13 +267,13 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         if (p->kv_cond[l]) {                                    // cross-attention: q from the modulated x, K|V from the condition
             const int S = p->cond_tokens;
             GemmArgs gq{BF(p->Hb), D, BF(p->w_q[l]), D, p->b_q[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, D};
-            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->kv_cond[l]), 2L * D, (long)S * 2 * D, BF(p->kv_cond[l]) + D, 2L * D,
                         BFM(p->Ob), p->batch, p->heads, T, S, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
         } else {                                                // self-attention: fused q|k|v projection of the modulated x
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
-            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
@@ -283,31 +283,32 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             // fc_o + gate + residual, also emitting Hb = x (1 + scale_mlp) and the row statistics; mlp.fc consumes them
             GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D,
                         BFM(p->Hb), D, m + 4 * D, tstr, p->stats};
-            LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
+            go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
             GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, nullptr, p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, F, D,
                         nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl + 6L * D, fl + 6L * D + F, fstep};
-            LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
+            gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
             GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F,
                         BFM(p->Hb), D, m + 6 * D + D, tstr, p->stats};      // next block's scale_msa
+            gd.max_wgs = p->gemm_wgs;
             if (l + 1 < p->blocks) LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
             else LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
             continue;
         }
         GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
-        LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
+        go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
         LnArgs n2{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m + 3 * D, m + 4 * D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n2, s));
         GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, p->b_up[l], p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, F, D};
-        LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_launch(LDT_EPI_GELU_BF16, &gu, s));
+        gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_launch(LDT_EPI_GELU_BF16, &gu, s));
         GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F};
-        LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
+        gd.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
     }
     {                                                           // FinalLayer (layers.py:240-248)
         const float* m = p->mod + (long)p->blocks * 6 * D;
         LnArgs nf{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&nf, s));
         GemmArgs gf{BF(p->Hb), D, BF(p->w_out), D, p->b_out, eps_out, p->z_dim, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, p->z_dim, D};
-        LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &gf, s));
+        gf.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &gf, s));
     }
     return LDT_OK;
 }

@@ -688,7 +688,8 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     }
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
-    const int grid = tiles < cap ? tiles : cap;                          // one persistent workgroup per CU
+    const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;
+    const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
     hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256");
 }

@@ -27,6 +27,7 @@ struct GemmArgs {
     // with (mean, rstd) of each row from stats_in[stats_parts][M][2] over the K input channels
     const float* stats_in; int stats_parts; const float* fold_S; const float* fold_C; long fold_step_stride;
     int group_m;                        // 256-tile kernel: row panels per group of the tile order (set by the launcher)
+    int max_wgs;                        // 256-tile kernel: cap on the persistent grid (0 = one workgroup per CU); sub-batch streams use 128
 };
 
 struct LnArgs {

@@ -12,9 +12,11 @@ part 4: var(1e-6) is exactly one ulp in fp32 and must not be recomputed with a d
   * generic loop — any other `score_fn(t, x, label=, condition=) -> (score, params)` callable is driven
     step by step from Python, the update still done by `ldt_sampler_step` (params, not score, feed it).
 Extra keyword-only arguments (not in the reference): `x0`, `noise` (inject the CPU draws for parity),
-`sample_offset` (global index of this rank's first sample, keeps Philox streams shard-invariant).
+`sample_offset` (global index of this rank's first sample, keeps Philox streams shard-invariant), `streams` (sub-batches
+sampled concurrently on their own HIP streams: default 2 when each half still fills half the chip, `LDT_STREAMS` overrides).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -109,7 +111,7 @@ class DiffusionVPSDE:
     @torch.no_grad()
     def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,
                         probability_flow, denoise, snr, device, condition=None, label=None, print_steps=None,
-                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None):
+                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None, streams=None):
         """Reverse-SDE predictor(-corrector) sampling, diffusion_continuous.py:133-338.
 
         corrector: None or 'ancestral' (AncestralCorrector :212-229; alpha = 1 by the reference's quirk Q11).
@@ -145,30 +147,88 @@ class DiffusionVPSDE:
         if model is not None and record is None and corrector is None and print_steps is None:
             from ._lib import CondArgs
             B, T = x.shape[0], x.shape[1]
-            eps_tmp = torch.empty_like(x)
-            counter = torch.zeros(1, dtype=torch.int32, device=dev)
             if use_graph is None:
                 use_graph = B * T <= 4096                                             # launch-bound regime only
-            cond_ref, keep = None, None
-            if condition is None and label is None:
-                _, mod = model.time_table(ts.to(dev))                                 # AdaLN rows for every step ...
-                fold = model.fold_table(mod) if model.can_fold(B, T) else None        # (+ the LN-folding S / C rows)
-                plan = model.plan(B, T, mod, model.n_mod, 0, fold=fold)               # ... shared by the batch
-            else:                                                                     # per-sample rows, rebuilt every step
-                extra, kv, S = model.condition_embedding(label, condition)
+            # Sub-batches on concurrent streams (trajectories are independent): with the persistent GEMM grids capped at
+            # half the chip each, one stream's HBM-bound phases (epilogues, attention) run beside the other's MFMA-bound
+            # main loops instead of all 256 CUs alternating between the two (measured -2.6 % per SDE step at B=64, T=256;
+            # a deliberate phase skew between the streams gained nothing, four quarter batches lose: too few tiles).  Only
+            # where a half batch still fills its half of the chip with whole 256x256 tiles.
+            if streams is None:
+                streams = int(os.environ.get("LDT_STREAMS", "0")) or (2 if (B % 2 == 0 and (B // 2) * T >= 8192) else 1)
+            streams = max(1, min(int(streams), B))
+            shared = condition is None and label is None
+            if shared:
+                _, mod = model.time_table(ts.to(dev))                                 # AdaLN rows for every step, shared by the batch
+            else:
+                extra, kv, S = model.condition_embedding(label, condition)            # per-sample rows, rebuilt every step
                 temb = model.time_embedding(ts.to(dev))
                 w_ada, b_ada = model.stacked_adaln()
-                c_buf = torch.empty((B, model.t_dim), dtype=torch.float32, device=dev)
-                mod = torch.empty((B, model.n_mod), dtype=torch.float32, device=dev)
-                plan = model.plan(B, T, mod, 0, model.n_mod, kv_cond=kv, cond_tokens=S)
-                cond = CondArgs(temb.data_ptr(), ops._p(extra), w_ada.data_ptr(), b_ada.data_ptr(), c_buf.data_ptr(),
-                                mod.data_ptr(), model.t_dim, model.n_mod)
-                cond_ref, keep = ctypes.byref(cond), (extra, temb, w_ada, b_ada, c_buf, mod, cond)
-            check(lib().ldt_sample_loop(ctypes.byref(plan), x.data_ptr(), x_mean.data_ptr(), eps_tmp.data_ptr(),
-                                        coef_d.data_ptr(), mode, ops._p(noise), nstride, elem_offset, seed,
-                                        counter.data_ptr(), N, cond_ref, int(bool(use_graph)), ops.stream_ptr()),
-                  "ldt_sample_loop")
-            torch.cuda.current_stream().synchronize() if keep is not None else None   # scratch must outlive the loop
+            bounds = [B * i // streams for i in range(streams + 1)]
+            jobs, keep = [], []
+            fold = None
+            for i in range(streams):
+                lo, hi = bounds[i], bounds[i + 1]
+                Bs = hi - lo
+                xs, xm = x[lo:hi], x_mean[lo:hi]                                      # contiguous row slices, updated in place
+                eps_tmp = torch.empty_like(xs)
+                counter = torch.zeros(1, dtype=torch.int32, device=dev)
+                nz = None if noise is None else noise[:, lo:hi]
+                wgs = 0 if streams == 1 else max(256 // streams, 1)
+                cond_ref = None
+                if shared:
+                    if fold is None and model.can_fold(Bs, T):
+                        fold = model.fold_table(mod)                                  # (+ the LN-folding S / C rows)
+                    plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if model.can_fold(Bs, T) else None, slot=i, gemm_wgs=wgs)
+                else:
+                    c_buf = torch.empty((Bs, model.t_dim), dtype=torch.float32, device=dev)
+                    modb = torch.empty((Bs, model.n_mod), dtype=torch.float32, device=dev)
+                    ex = None if extra is None else extra[lo:hi].contiguous()
+                    kvs = None if kv is None else {l: t.view(B, S, -1)[lo:hi].reshape(Bs * S, -1) for l, t in kv.items()}
+                    plan = model.plan(Bs, T, modb, 0, model.n_mod, kv_cond=kvs, cond_tokens=S, slot=i, gemm_wgs=wgs)
+                    cond = CondArgs(temb.data_ptr(), ops._p(ex), w_ada.data_ptr(), b_ada.data_ptr(), c_buf.data_ptr(),
+                                    modb.data_ptr(), model.t_dim, model.n_mod)
+                    cond_ref = ctypes.byref(cond)
+                    keep.append((ex, kvs, c_buf, modb, cond))
+                if nz is not None and streams > 1:
+                    nz = nz.contiguous()                                              # [N, Bs, T, z] with step stride Bs*T*z
+                jobs.append((plan, xs, xm, eps_tmp, counter, nz, cond_ref, elem_offset + lo * int(np.prod(shape))))
+
+            def run(job, stream):
+                plan, xs, xm, eps_tmp, counter, nz, cond_ref, off = job
+                with torch.cuda.stream(stream):
+                    check(lib().ldt_sample_loop(ctypes.byref(plan), xs.data_ptr(), xm.data_ptr(), eps_tmp.data_ptr(),
+                                                coef_d.data_ptr(), mode, ops._p(nz), xs.numel() if nz is not None else 0, off, seed,
+                                                counter.data_ptr(), N, cond_ref, int(bool(use_graph)), ops.stream_ptr()),
+                          "ldt_sample_loop")
+
+            main = torch.cuda.current_stream()
+            if streams == 1:
+                run(jobs[0], main)
+            else:
+                import threading
+                subs = [torch.cuda.Stream(device=dev) for _ in jobs]
+                errs = []
+
+                def worker(job, st):
+                    try:
+                        torch.cuda.set_device(dev)
+                        st.wait_stream(main)                                          # tables / x0 were produced on the caller's stream
+                        run(job, st)
+                    except BaseException as e:                                        # noqa: BLE001 - re-raised on the caller's thread
+                        errs.append(e)
+
+                th = [threading.Thread(target=worker, args=(j, st)) for j, st in zip(jobs, subs)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()                                                         # (ctypes releases the GIL inside the C call)
+                if errs:
+                    raise errs[0]
+                for st in subs:
+                    main.wait_stream(st)
+            if keep or streams > 1:
+                main.synchronize()                                                    # scratch / sub-streams must outlive the loop
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)

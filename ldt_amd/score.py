@@ -179,25 +179,29 @@ class Score(nn.Module):
             self._cond_cache = {key: (kv, S)}
         return self._cond_cache[key]
 
-    def _workspace(self, B, T):
-        k = (B, T, self._device())
+    def _workspace(self, B, T, slot=0):
+        """Activation buffers of a (B, T) batch; `slot` separates the sub-batches that run concurrently on their own streams."""
+        k = (B, T, self._device(), slot)
         if k not in self._ws:
             dev, M, D = self._device(), B * T, self.hidden_size
             bf = dict(dtype=torch.bfloat16, device=dev)
-            self._ws = {k: {
+            self._ws = {kk: v for kk, v in self._ws.items() if kk[:3] == k[:3]}     # keep only this shape's slots
+            self._ws[k] = {
                 "xin": torch.zeros((M, ops.pad64(self.z_dim)), **bf),
                 "X": torch.empty((M, D), dtype=torch.float32, device=dev),
                 "Hb": torch.empty((M, D), **bf), "QKV": torch.empty((M, 3 * D), **bf),
                 "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
                 "stats": torch.empty((max(D // 256, 1), M, 2), dtype=torch.float32, device=dev),
-            }}
+            }
         return self._ws[k]
 
-    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None):
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0):
         """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows};
-        fold: the `fold_table(mod)` of a batch-shared `mod` (enables the LN-folded GEMM epilogues)."""
-        P, W = self.packed(), self._workspace(B, T)
+        fold: the `fold_table(mod)` of a batch-shared `mod` (enables the LN-folded GEMM epilogues); slot / gemm_wgs: workspace
+        set and persistent-grid cap of a sub-batch that shares the GPU with another stream (diffusion.py, `streams`)."""
+        P, W = self.packed(), self._workspace(B, T, slot)
         p = ScorePlan()
+        p.gemm_wgs = gemm_wgs
         p.hidden, p.heads, p.blocks = self.hidden_size, self.num_heads, self.num_blocks
         p.z_dim, p.z_pad, p.mlp_hidden = self.z_dim, ops.pad64(self.z_dim), W["U"].shape[1]
         p.tokens, p.batch = T, B

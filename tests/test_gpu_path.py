@@ -292,6 +292,31 @@ def test_lnfold_sampler_vs_oracle_and_unfolded(monkeypatch):
     assert rel_mse(folded.cpu(), plain.cpu()) < TOL_LATENT
 
 
+def test_substreams_equal_single_stream(env, monkeypatch):
+    """Sub-batches sampled on two concurrent HIP streams (two host threads, each with its own plan, workspace and step
+    counter) give the same latents as one stream — injected noise and device Philox noise (keyed by global element index),
+    unconditional and conditioned."""
+    tg, tr, cfg = env["tg"], env["tr"], env["cfg"]
+    g = torch.Generator().manual_seed(9)
+    B = 6
+    x0 = torch.randn(B, cfg.score.z_scale, cfg.score.z_dim, generator=g)
+    kw = dict(score_fn=tr.score_fn, num_samples=B, N=cfg.sde.sample_N, predictor="ancestral", corrector=None, corrector_steps=1,
+              shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=False, denoise=True,
+              snr=0.01, device="cuda:0", x0=x0)
+    noise = torch.randn(cfg.sde.sample_N, B, cfg.score.z_scale, cfg.score.z_dim, generator=g)
+    a, _ = load_golden("score_tiny")
+    pts = torch.randn(B, cfg.score.hidden_size, 5, generator=g).cuda(); img = torch.randn(B, cfg.score.t_dim, generator=g).cuda()
+    for extra in (dict(noise=noise), dict(seed=123), dict(seed=7, condition=(pts, img))):
+        one = tr.SDE.sample_discrete(**kw, **extra, streams=1)
+        two = tr.SDE.sample_discrete(**kw, **extra, streams=2)
+        three = tr.SDE.sample_discrete(**kw, **extra, streams=3)
+        assert torch.isfinite(one).all()
+        assert rel_mse(two.cpu(), one.cpu()) < 1e-6 and rel_mse(three.cpu(), one.cpu()) < 1e-6
+    monkeypatch.setenv("LDT_STREAMS", "2")
+    env_two = tr.SDE.sample_discrete(**kw, seed=123)
+    assert rel_mse(env_two.cpu(), tr.SDE.sample_discrete(**kw, seed=123, streams=1).cpu()) < 1e-6
+
+
 def test_ema_swap_repacks_weights(env):
     """EMA swap (tools/utils.py:80-101) re-points parameters; the packed bf16 panels must follow."""
     ldt, cfg = env["ldt"], env["cfg"]
