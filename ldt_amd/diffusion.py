@@ -13,7 +13,7 @@ part 4: var(1e-6) is exactly one ulp in fp32 and must not be recomputed with a d
     step by step from Python, the update still done by `ldt_sampler_step` (params, not score, feed it).
 Extra keyword-only arguments (not in the reference): `x0`, `noise` (inject the CPU draws for parity),
 `sample_offset` (global index of this rank's first sample, keeps Philox streams shard-invariant), `streams` (sub-batches
-sampled concurrently on their own HIP streams: default 2 when each half still fills half the chip, `LDT_STREAMS` overrides).
+sampled concurrently on their own HIP streams; default 1, `LDT_STREAMS=2` measured -2.6 % per step at B=64, T=256).
 """
 import ctypes
 import os
@@ -154,8 +154,8 @@ class DiffusionVPSDE:
             # main loops instead of all 256 CUs alternating between the two (measured -2.6 % per SDE step at B=64, T=256;
             # a deliberate phase skew between the streams gained nothing, four quarter batches lose: too few tiles).  Only
             # where a half batch still fills its half of the chip with whole 256x256 tiles.
-            if streams is None:
-                streams = int(os.environ.get("LDT_STREAMS", "0")) or (2 if (B % 2 == 0 and (B // 2) * T >= 8192) else 1)
+            if streams is None:                                                       # opt-in: per-kernel accounting (bench roofline,
+                streams = int(os.environ.get("LDT_STREAMS", "1"))                     # rocprof) stays one launch = the whole batch
             streams = max(1, min(int(streams), B))
             shared = condition is None and label is None
             if shared:
@@ -177,9 +177,9 @@ class DiffusionVPSDE:
                 wgs = 0 if streams == 1 else max(256 // streams, 1)
                 cond_ref = None
                 if shared:
-                    if fold is None and model.can_fold(Bs, T):
+                    if fold is None and model.can_fold(Bs, T, wgs):
                         fold = model.fold_table(mod)                                  # (+ the LN-folding S / C rows)
-                    plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if model.can_fold(Bs, T) else None, slot=i, gemm_wgs=wgs)
+                    plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if model.can_fold(Bs, T, wgs) else None, slot=i, gemm_wgs=wgs)
                 else:
                     c_buf = torch.empty((Bs, model.t_dim), dtype=torch.float32, device=dev)
                     modb = torch.empty((Bs, model.n_mod), dtype=torch.float32, device=dev)

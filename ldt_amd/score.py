@@ -254,14 +254,17 @@ class Score(nn.Module):
         ops.sgemm(c, lin.weight, lin.bias, act_in=ACT_SILU, out=mod[:, self.num_blocks * 6 * D:])
         return c, mod
 
-    def can_fold(self, B, T):
-        """LN folding pays when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs fill the chip
-        (>= 128 tiles).  LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
+    def can_fold(self, B, T, gemm_wgs=0):
+        """LN folding pays when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs' tiles fill at
+        least 5/8 of the workgroups they may use (all 256 CUs, or a sub-batch stream's share `gemm_wgs`) — the same rule
+        by which ldt_gemm_launch prefers the 256^2 kernel; at M = 8192 on the whole chip the 128^2 kernel + LayerNorm
+        launches measured 3 % faster.  LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
         if mode == 0 or self.unet or D % 256 or D > 1024 or M % 256 or self.Transformer[0].mlp.out.in_channels % 256:
             return False
-        return mode == 2 or (M // 256) * (D // 256) >= 128
+        lim = gemm_wgs if 0 < gemm_wgs < 256 else 256
+        return mode == 2 or (M // 256) * (D // 256) * 8 >= lim * 5
 
     def fold_table(self, mod):
         """Per-step S / C vectors of the LN-folded projections (include/ldt_hip.h, ldt_gemm_resid_lnstats), fp32
