@@ -274,6 +274,10 @@ int ldt_sample_loop(const ldt_score_plan* plan, float* x, float* x_mean, float* 
                     int64_t elem_offset, uint64_t seed, int32_t* step_counter, int32_t n_steps,
                     const ldt_cond_args* cond, int32_t use_graph, void* stream);
 
+/* ---- measurement knob (tools/dbg/gm_bench.py): rows per group of the persistent GEMM's grouped tile order
+ * (1 = row-major, the default; LDT_GEMM_GM sets it at start-up).  Process-wide; not used by the product path. */
+int ldt_dbg_gemm_group_m(int32_t rows_per_group);
+
 #ifdef __cplusplus
 }
 #endif

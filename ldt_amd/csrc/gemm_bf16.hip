@@ -671,7 +671,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 
 // rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
 static int g_group_m = -1;
-extern "C" void ldt_dbg_gemm_group_m(int gm) { g_group_m = gm; }
+extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m = gm; return LDT_OK; }
 
 template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {

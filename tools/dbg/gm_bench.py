@@ -7,7 +7,6 @@ from ldt_amd._lib import EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32
 M = int(os.environ.get("M", 16384))
 shapes = [("qkv", 3072, 1024, EPI_BF16), ("up", 4096, 1024, EPI_GELU_BF16), ("dn", 1024, 4096, EPI_RESID_F32), ("o", 1024, 1024, EPI_RESID_F32)]
 h = _lib.lib()
-h.ldt_dbg_gemm_group_m.argtypes = [ctypes.c_int]; h.ldt_dbg_gemm_group_m.restype = None
 torch.manual_seed(0)
 for name, N, K, epi in shapes:
     x = (torch.randn(M, K, device="cuda")).to(torch.bfloat16); w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
