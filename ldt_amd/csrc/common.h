@@ -28,7 +28,7 @@ int ldt_check_launch(const char* what);   // hipGetLastError -> status (+ messag
         }                                     \
     } while (0)
 
-static inline bool ldt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ static inline bool ldt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

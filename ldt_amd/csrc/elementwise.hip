@@ -282,15 +282,25 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const SgemmArgs a) {
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     float acc[4][4] = {};
     const int lr = tid >> 2, lk = (tid & 3) * 4;
+    // each thread stages 4 consecutive k of one A row and one B row: one 16-B load each when the rows allow it
+    const bool vec = (a.lda % 4 == 0) && (a.ldb % 4 == 0) && (a.K % 4 == 0) && ldt_aligned16(a.A) && ldt_aligned16(a.B);
     for (int k0 = 0; k0 < a.K; k0 += 16) {
+        const int m = m0 + lr, n = n0 + lr, kk = k0 + lk;
+        f32x4 va4 = {0.f, 0.f, 0.f, 0.f}, vb4 = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            if (m < a.M && kk < a.K) va4 = *reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + kk);
+            if (n < a.N && kk < a.K) vb4 = *reinterpret_cast<const f32x4*>(a.B + (long)n * a.ldb + kk);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (m < a.M && kk + j < a.K) va4[j] = a.A[(long)m * a.lda + kk + j];
+                if (n < a.N && kk + j < a.K) vb4[j] = a.B[(long)n * a.ldb + kk + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = k0 + lk + j;
-            const int m = m0 + lr, n = n0 + lr;
-            float va = (m < a.M && k < a.K) ? a.A[(long)m * a.lda + k] : 0.f;
-            if (a.act_in) va = apply_act(va, a.act_in);
-            As[lk + j][lr] = va;
-            Bs[lk + j][lr] = (n < a.N && k < a.K) ? a.B[(long)n * a.ldb + k] : 0.f;
+            As[lk + j][lr] = a.act_in ? apply_act(va4[j], a.act_in) : va4[j];
+            Bs[lk + j][lr] = vb4[j];
         }
         __syncthreads();
 #pragma unroll
