@@ -240,3 +240,27 @@ def test_condition_net_parameter_tree(tiny_cfg):
     assert list(score.state_dict())[0].startswith("c_net.")            # built before the Transformer, as upstream
     with pytest.raises(RuntimeError):
         score.c_net({"pts": torch.zeros(1, 96, 3)})                    # CPU tensors/params: no fallback
+
+
+def test_gelu_epilogue_form_accuracy():
+    """The GEMM epilogue's GELU (`gelu_erf_fast`, ldt_amd/csrc/common.h): x/2 + |x| (1/2 - 2^(-z p(z)) / 2) with the
+    coefficients read from the header, evaluated in float32 exactly as the kernel does, against the exact erf GELU the
+    reference uses (nn.GELU(), tools/utils.py:107-108): max |error| <= 1e-6 for every finite x, no NaN/inf at extremes."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ldt_amd", "csrc", "common.h")).read()
+    c = [np.float32(float(re.search(r"#define LDT_GELU_C%d \(?(-?[0-9.e-]+)f\)?" % i, src).group(1))) for i in range(1, 6)]
+    with np.errstate(over="ignore"):
+        x = np.concatenate([np.linspace(-14, 14, 560001), [-3e38, -1e30, -1e10, -1e4, -100., 100., 1e4, 1e10, 1e30, 3e38, 0.0, -0.0,
+                                                              1e-20, -1e-20]]).astype(np.float32)
+        z = np.abs(x)
+        p = (((c[4] * z + c[3]) * z + c[2]) * z + c[1]) * z + c[0]
+        e = np.exp2(-(p * z)).astype(np.float32)
+        y = x * np.float32(0.5) + z * (np.float32(0.5) - np.float32(0.5) * e)
+    assert np.isfinite(y).all()
+    ref = 0.5 * x.astype(np.float64) * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    small = np.abs(x) < 1e4
+    assert np.abs(y[small] - ref[small]).max() <= 1e-6
+    assert np.allclose(y[~small], ref[~small], rtol=1e-6)
