@@ -755,9 +755,12 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }
     }
-    // v1 tile shape: the largest of 128x128 / 128x64 / 64x64 that still gives every CU a tile
+    // v1 tile shape: the largest of 128x128 / 128x64 / 64x64 that still gives every CU two tiles
     auto ntiles = [&](int bm, int bn) { return (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
-    const int shape = (force == 128 || ntiles(128, 128) >= LDT_NUM_CUS) ? 0 : (ntiles(128, 64) >= LDT_NUM_CUS ? 1 : 2);
+    static const int v1_shape = getenv("LDT_GEMM_V1_SHAPE") ? atoi(getenv("LDT_GEMM_V1_SHAPE")) : -1;   // tools/dbg
+    // this 2-phase kernel hides a stage's load latency only across co-resident workgroups: want >= 2 tiles per CU
+    // (M = 2048: QKV 25.8 -> 22.9 us with 128x64, fc_o 14.4 -> 12.0 and mlp.out 47.7 -> 40.0 us with 64x64 tiles)
+    const int shape = v1_shape >= 0 ? v1_shape : (force == 128 || ntiles(128, 128) >= 2 * LDT_NUM_CUS) ? 0 : (ntiles(128, 64) >= 2 * LDT_NUM_CUS ? 1 : 2);
     dim3 block(256);
 #define LAUNCH_V1(E)                                                                                                     \
     do {                                                                                                                 \
