@@ -49,12 +49,16 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
 
 // TBM x TBN output tile (each 128 or 64): 128x128 is the workhorse of mid-size problems, the smaller shapes keep all
 // 256 CUs busy when M*N is small (T=32 latents: M = 2048 rows).
-template <int EPI, int TBM, int TBN>
+// NST = 2: a stage is waited for in full before the barrier (the simple 2-phase loop).  NST = 3: the DMA of stage
+// kt+2 stays in flight across the barrier (counted vmcnt, raw s_barrier), which hides the load latency when only 1-3
+// workgroups share a CU (small M: the T = 32 latents, half-batch shapes).
+template <int EPI, int TBM, int TBN, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     constexpr int BM = TBM, BN = TBN;
     constexpr int XB = TBM * BK * 2, WB = TBN * BK * 2;               // operand tile bytes per stage
     constexpr int MT = TBM / 32, NT = TBN / 32;                       // 16x16 accumulator tiles per wave (m, n)
-    __shared__ __attribute__((aligned(16))) char smem[2 * (XB + WB)];  // [stage][X|W]
+    constexpr int OPS = TBM / 32 + TBN / 32;                          // LDS-DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(16))) char smem[NST * (XB + WB)];  // [stage][X|W]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,8 +82,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const int nk = a.K / BK;
     stage_tile<TBM>(a.X, a.ldx, m0, a.M, 0, smem, wave, lane);
     stage_tile<TBN>(a.W, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // stages 1 .. NST-2 follow at once; wait until only they are outstanding (stage 0 landed)
+    int ahead = 0;                                                    // stages issued beyond the one being waited for
+#pragma unroll
+    for (int st = 1; st < NST - 1; ++st)
+        if (st < nk) {
+            stage_tile<TBM>(a.X, a.ldx, m0, a.M, st * BK, smem + st * (XB + WB), wave, lane);
+            stage_tile<TBN>(a.W, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
+            ++ahead;
+        }
+    if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+    else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     const int lrow = lane & 15;
     const int lchk = lane >> 4;
@@ -87,10 +102,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         char* sx = smem + cur * (XB + WB);
         char* sw = sx + XB;
-        if (kt + 1 < nk) {
-            char* nx = smem + (cur ^ 1) * (XB + WB);
-            stage_tile<TBM>(a.X, a.ldx, m0, a.M, (kt + 1) * BK, nx, wave, lane);
-            stage_tile<TBN>(a.W, a.ldw, n0, a.N, (kt + 1) * BK, nx + XB, wave, lane);
+        if (kt + NST - 1 < nk) {                                      // buffer of stage kt-1 (NST = 3) / kt+1's own (NST = 2)
+            int nb = cur + NST - 1; nb = nb >= NST ? nb - NST : nb;
+            char* nx = smem + nb * (XB + WB);
+            stage_tile<TBM>(a.X, a.ldx, m0, a.M, (kt + NST - 1) * BK, nx, wave, lane);
+            stage_tile<TBN>(a.W, a.ldw, n0, a.N, (kt + NST - 1) * BK, nx + XB, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -112,9 +128,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
                 for (int mi = 0; mi < MT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+        // stage kt+1 landed (only the stages behind it, kt+2 .. kt+NST-1, may still be in flight), then visible to every wave
+        const int left = nk - 2 - kt;                                 // stages that exist beyond kt+1
+        if (NST >= 4 && left >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+        else if (NST >= 3 && left >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
 
     // ---- epilogue: lane holds D[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)], r = 0..3 ----
@@ -762,9 +782,17 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     // (M = 2048: QKV 25.8 -> 22.9 us with 128x64, fc_o 14.4 -> 12.0 and mlp.out 47.7 -> 40.0 us with 64x64 tiles)
     const int shape = v1_shape >= 0 ? v1_shape : (force == 128 || ntiles(128, 128) >= 2 * LDT_NUM_CUS) ? 0 : (ntiles(128, 64) >= 2 * LDT_NUM_CUS ? 1 : 2);
     dim3 block(256);
+    // 3 stages only for 64x64 tiles (48 KB of LDS, still 3 workgroups per CU; M = 2048: fc_o 13.5 -> 12.3, mlp.out 38.6 ->
+    // 31.3 us; a 4th stage measured equal): at 128x64 / 128x128 the third buffer costs a co-resident workgroup and loses 20-40 %
+    static const int v1_stages_env = getenv("LDT_GEMM_V1_STAGES") ? atoi(getenv("LDT_GEMM_V1_STAGES")) : 0;   // tools/dbg
+    const int v1_stages = v1_stages_env ? v1_stages_env : (shape == 2 ? 3 : 2);
 #define LAUNCH_V1(E)                                                                                                     \
     do {                                                                                                                 \
-        if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128>), dim3((unsigned)ntiles(128, 128)), block, 0, stream, *a); \
+        if (v1_stages >= 3) {                                                                                            \
+            if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128, 3>), dim3((unsigned)ntiles(128, 128)), block, 0, stream, *a); \
+            else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 64, 3>), dim3((unsigned)ntiles(128, 64)), block, 0, stream, *a); \
+            else hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 64, 64, 3>), dim3((unsigned)ntiles(64, 64)), block, 0, stream, *a);  \
+        } else if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128>), dim3((unsigned)ntiles(128, 128)), block, 0, stream, *a); \
         else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 64>), dim3((unsigned)ntiles(128, 64)), block, 0, stream, *a); \
         else hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 64, 64>), dim3((unsigned)ntiles(64, 64)), block, 0, stream, *a);  \
     } while (0)
