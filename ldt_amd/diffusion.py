@@ -107,6 +107,44 @@ class DiffusionVPSDE:
         coef = torch.stack([A, Bc, Cc, torch.zeros_like(A)], 1).float()
         return ts, coef.contiguous(), 1
 
+    # ---- probability-flow ODE sampling (sample_mode: continuous) -----------------------------------------
+    @torch.no_grad()
+    def sample_model_ode(self, score_fn, num_samples, shape, ode_eps, ode_solver_tol, enable_autocast=False, noise=None,
+                         condition=None, label=None, *, device="cuda"):
+        """diffusion_continuous.py:88-131: dx/dt = f(t) x - g2(t)/2 * score, from t = 1 to `ode_eps`, solved the way the
+        reference's `torchdiffeq.odeint(method="scipy_solver", options={"solver": "RK45"})` does it: scipy's RK45 on the
+        host over the flattened float64 state, time reversed to increasing s = -t, rtol = atol = `ode_solver_tol`; every
+        function evaluation is one Score forward on the GPU (`score_fn(t, x)` with t a (B,) vector, as upstream).
+        Returns (samples, nfe_count, seconds) like the reference.  `noise` defaults to a CPU-generator draw (the reference
+        draws on the CUDA generator, :107 — not reproducible across devices either way).
+        NB the bf16 Score limits the smoothness the step controller sees to ~1e-3 relative: tolerances much below that
+        (the shipped `ode_tol: 1e-5`) are met only by many small steps.  torchdiffeq is not vendored upstream: its wrapper's
+        behaviour is restated (oracle/ldt_oracle.py::sample_model_ode) — parity unpinned."""
+        import time
+        from scipy.integrate import solve_ivp
+        if self.sde_type != "vpsde":
+            raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % (self.sde_type,))
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("sample_model_ode: device %s — the HIP path has no CPU fallback" % (device,))
+        x0 = torch.randn((num_samples,) + tuple(shape)) if noise is None else noise
+        full = tuple(x0.shape)
+        nfe = [0]
+
+        def fun(s, y):
+            t = torch.full((full[0],), -float(s), dtype=torch.float32, device=dev)
+            x = torch.from_numpy(y).to(dev, torch.float32).reshape(full)
+            score, _ = score_fn(t, x, label=label, condition=condition)
+            dx = self.f(t)[:, None, None] * x - 0.5 * self.g2(t)[:, None, None] * score
+            nfe[0] += 1
+            return (-dx).reshape(-1).double().cpu().numpy()
+
+        t0 = time.time()
+        sol = solve_ivp(fun, t_span=[-1.0, -float(ode_eps)], y0=x0.reshape(-1).double().cpu().numpy(),
+                        t_eval=[-1.0, -float(ode_eps)], method="RK45", rtol=ode_solver_tol, atol=ode_solver_tol)
+        out = torch.from_numpy(sol.y[:, -1]).to(dev, torch.float32).reshape(full)
+        return out, nfe[0], time.time() - t0
+
     # ---- the sampler --------------------------------------------------------------------------------
     @torch.no_grad()
     def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,

@@ -81,9 +81,8 @@ class Trainer:
         self.compressor.eval()
         self.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
         try:
-            if self.sample_mode != "discrete":
-                raise NotImplementedError("sample_mode 'continuous' (ODE, needs torchdiffeq) is out of scope; "
-                                          "the shipped config uses 'discrete'")
+            if self.sample_mode not in ("discrete", "continuous"):
+                raise NotImplementedError("sample_mode %r" % (self.sample_mode,))
             cs = self.cfg.score
             shape = (cs.z_scale, cs.z_dim + 3 if getattr(cs, "graphconv", False) else cs.z_dim)
             rank, ws = ldist.world()
@@ -102,14 +101,19 @@ class Trainer:
                     condition = tuple(_rows(c, lo, hi, per) if torch.is_tensor(c) else c for c in condition)
                 elif isinstance(condition, dict):        # raw ViPC inputs {'img','pts'}: ConditionNet runs on this rank's rows
                     condition = {k: _rows(v, lo, hi, per) if torch.is_tensor(v) else v for k, v in condition.items()}
-            eps = self.SDE.sample_discrete(score_fn=self.score_fn, N=self.cfg.sde.sample_N,
-                                           corrector=self.cfg.sde.corrector, predictor=self.cfg.sde.predictor,
-                                           corrector_steps=self.cfg.sde.corrector_steps, shape=shape,
-                                           time_eps=self.sample_time_eps, label=label, denoise=self.cfg.sde.denoise,
-                                           device=self.device, num_samples=per,
-                                           probability_flow=self.cfg.sde.probability_flow, snr=self.cfg.sde.snr,
-                                           condition=condition, x0=x0_loc, noise=noise_loc, sample_offset=lo,
-                                           seed=seed, use_graph=use_graph)
+            if self.sample_mode == "continuous":             # probability-flow ODE (Latent_SDE_Trainer.py:148-152)
+                eps, self.nfe_count, _ = self.SDE.sample_model_ode(
+                    score_fn=self.score_fn, num_samples=per, shape=(cs.z_scale, cs.z_dim), label=label, ode_eps=self.sample_time_eps,
+                    enable_autocast=False, ode_solver_tol=self.cfg.sde.ode_tol, condition=condition, noise=x0_loc, device=self.device)
+            else:
+                eps = self.SDE.sample_discrete(score_fn=self.score_fn, N=self.cfg.sde.sample_N,
+                                               corrector=self.cfg.sde.corrector, predictor=self.cfg.sde.predictor,
+                                               corrector_steps=self.cfg.sde.corrector_steps, shape=shape,
+                                               time_eps=self.sample_time_eps, label=label, denoise=self.cfg.sde.denoise,
+                                               device=self.device, num_samples=per,
+                                               probability_flow=self.cfg.sde.probability_flow, snr=self.cfg.sde.snr,
+                                               condition=condition, x0=x0_loc, noise=noise_loc, sample_offset=lo,
+                                               seed=seed, use_graph=use_graph)
             npts = self.num_points if num_points is None else num_points
             sample = self.compressor.sample((per, npts), given_eps=eps)
             if ws > 1:                                   # the single collective of the path

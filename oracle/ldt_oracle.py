@@ -540,6 +540,31 @@ def draw_noises(seed, B, T, z, N):
     return x0, noises
 
 
+def sample_model_ode(sde, score_fn, noise, ode_eps, ode_solver_tol, nfe=None):
+    """diffusion/diffusion_continuous.py:88-131 (sample_model_ode): probability-flow ODE dx/dt = f(t) x - g2(t)/2 score
+    integrated from t = 1 to ode_eps by `torchdiffeq.odeint(..., method="scipy_solver", options={"solver": "RK45"})`.
+    torchdiffeq (requirements.txt:9, version unpinned) is NOT vendored: this restates what its scipy wrapper does with
+    those arguments — decreasing times are solved as increasing s = -t with the negated function
+    (odeint's time reversal), the state is flattened to a float64 numpy vector, scipy.integrate.solve_ivp(RK45) runs with
+    rtol = atol = ode_solver_tol, every function evaluation converts to float32 tensors and back — **parity unpinned**.
+    noise [B,T,z] is the initial state (the reference draws it on the GPU generator, :107).  Returns the state at ode_eps."""
+    from scipy.integrate import solve_ivp
+    shape = tuple(noise.shape)
+
+    def fun(s, y):
+        t = torch.tensor(-s, dtype=torch.float32).expand(shape[0])
+        x = torch.from_numpy(np.asarray(y)).to(torch.float32).reshape(shape)
+        score, _ = score_fn(t, x)
+        dx = sde.f(t)[:, None, None] * x - 0.5 * sde.g2(t)[:, None, None] * score       # :102
+        if nfe is not None:
+            nfe.append(1)
+        return (-dx).reshape(-1).double().numpy()
+
+    sol = solve_ivp(fun, t_span=[-1.0, -float(ode_eps)], y0=noise.reshape(-1).double().numpy(), t_eval=[-1.0, -float(ode_eps)],
+                    method="RK45", rtol=ode_solver_tol, atol=ode_solver_tol)
+    return torch.from_numpy(sol.y[:, -1]).to(torch.float32).reshape(shape)
+
+
 # ----------------------------------------------------------------------------- validation metrics (evaluation/)
 
 

@@ -317,6 +317,35 @@ def test_substreams_equal_single_stream(env, monkeypatch):
     assert rel_mse(env_two.cpu(), tr.SDE.sample_discrete(**kw, seed=123, streams=1).cpu()) < 1e-6
 
 
+def test_ode_sampling_mode_vs_oracle(env):
+    """sample_mode 'continuous' (sample_model_ode, diffusion_continuous.py:88-131): scipy RK45 on the host driving the HIP
+    Score, against the oracle's restatement with the CPU Score on the same initial noise.  Both are adaptive solvers fed
+    with slightly different function values (bf16 vs fp32), so the accepted steps may differ: the bar is the solver's own
+    tolerance scale, not the per-step bf16 bar."""
+    tr, cfg, O = env["tr"], env["cfg"], env["O"]
+    g = torch.Generator().manual_seed(21)
+    B, T, z = 2, cfg.score.z_scale, cfg.score.z_dim
+    x1 = torch.randn(B, T, z, generator=g)
+    tol, eps = 1e-3, 1e-2
+    out, nfe, secs = tr.SDE.sample_model_ode(tr.score_fn, B, (T, z), eps, tol, noise=x1, device="cuda:0")
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(env["ssd"], cfg.score, x, t))
+    cnt = []
+    ref = O.sample_model_ode(sde, fn, x1, eps, tol, nfe=cnt)
+    assert out.shape == ref.shape and torch.isfinite(out).all() and nfe >= 7 and secs > 0
+    assert rel_mse(out.cpu(), ref) < 1e-3, (rel_mse(out.cpu(), ref), nfe, len(cnt))
+    # Trainer.sample in continuous mode returns decoded points of the ODE latents
+    old_mode = tr.sample_mode
+    try:
+        tr.sample_mode = "continuous"
+        tr.sample_time_eps, keep = eps, tr.sample_time_eps
+        cfg.sde.ode_tol, keep_tol = tol, cfg.sde.ode_tol
+        pts, lat = tr.sample(B, x0=x1)
+        assert rel_mse(lat.cpu(), out.cpu()) < 1e-6 and pts.shape[0] == B and torch.isfinite(pts).all()
+    finally:
+        tr.sample_mode, tr.sample_time_eps, cfg.sde.ode_tol = old_mode, keep, keep_tol
+
+
 def test_ema_swap_repacks_weights(env):
     """EMA swap (tools/utils.py:80-101) re-points parameters; the packed bf16 panels must follow."""
     ldt, cfg = env["ldt"], env["cfg"]

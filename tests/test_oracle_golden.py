@@ -270,3 +270,25 @@ def test_emd_approxmatch_properties():
     assert (same < 0.05 * exact[:2]).all(), same
     perm = torch.randperm(x.shape[1], generator=torch.Generator().manual_seed(0))
     assert torch.allclose(O.emd_approxmatch_cost(x[:2][:, perm], y[:2]), O.emd_approxmatch_cost(x[:2], y[:2]), rtol=1e-4)
+
+
+def test_ode_sampler_restatement_analytic():
+    """oracle.sample_model_ode (probability-flow ODE through scipy RK45 in reversed time, diffusion_continuous.py:88-131)
+    on a case with a closed form: data = a point mass at 0 gives score(t, x) = -x / var(t), and the flow then carries
+    x(1) to x(1) * std(eps) / std(1); data ~ N(0, I) gives score = -x and a constant state."""
+    import json, os
+    from conftest import GOLDEN, to_ns
+    from oracle import ldt_oracle as O
+    with open(os.path.join(GOLDEN, "tiny_cfg.json")) as f:
+        cfg = to_ns(json.load(f))
+    sde = O.VPSDE(cfg.sde)
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn(3, 4, 5, generator=g)
+    eps = 1e-2
+    nfe = []
+    out = O.sample_model_ode(sde, lambda t, x: (-x / sde.var(t)[:, None, None], None), x1, eps, 1e-7, nfe=nfe)
+    t1, te = torch.tensor(1.0), torch.tensor(eps)
+    ref = x1 * sde.std(te) / sde.std(t1)
+    assert rel_mse(out, ref) < 1e-8 and len(nfe) > 6
+    const = O.sample_model_ode(sde, lambda t, x: (-x, None), x1, eps, 1e-7)
+    assert rel_mse(const, x1) < 1e-10
