@@ -119,7 +119,7 @@ class DiffusionVPSDE:
         draws on the CUDA generator, :107 — not reproducible across devices either way).
         NB the bf16 Score limits the smoothness the step controller sees to ~1e-3 relative: tolerances much below that
         (the shipped `ode_tol: 1e-5`) are met only by many small steps.  torchdiffeq is not vendored upstream: its wrapper's
-        behaviour is restated (oracle/ldt_oracle.py::sample_model_ode) — parity unpinned."""
+        behaviour is restated from its published semantics — parity unpinned."""
         import time
         from scipy.integrate import solve_ivp
         if self.sde_type != "vpsde":
