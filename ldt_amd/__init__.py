@@ -1,7 +1,7 @@
 """ldt_amd — MI355X-native sampling hot path of LDT (Latent Diffusion Transformer for point clouds).
 
 Public surface mirrors the reference's classes on this path:
-    Score (+ ConditionNet), Compressor, DiffusionVPSDE, Trainer, dict2namespace
+    Score (+ ConditionNet), Compressor, DiffusionVPSDE, Trainer (+ CompletionTrainer), dict2namespace
 All arithmetic runs in hand-written HIP kernels (libldt_hip.so, C-ABI in include/ldt_hip.h).
 """
 from .compressor import Compressor
@@ -10,7 +10,7 @@ from .config import airplane_config, dict2namespace, load_config
 from .diffusion import DiffusionVPSDE, make_diffusion
 from . import metrics
 from .score import Score
-from .trainer import EMAWeights, Trainer
+from .trainer import CompletionTrainer, EMAWeights, Trainer
 
-__all__ = ["Score", "Compressor", "ConditionNet", "DiffusionVPSDE", "make_diffusion", "Trainer", "EMAWeights", "dict2namespace",
+__all__ = ["Score", "Compressor", "ConditionNet", "DiffusionVPSDE", "make_diffusion", "Trainer", "CompletionTrainer", "EMAWeights", "dict2namespace",
            "airplane_config", "load_config", "metrics"]

@@ -31,6 +31,23 @@ def distChamfer(a, b):
     return ops.chamfer(_dev(a), _dev(b))
 
 
+def L2_ChamferEval_1000(array1, array2):
+    """completion_trainer/Latent_SDE_Trainer.py:41-44: (mean dist1 + mean dist2) * 1000 over the whole batch."""
+    dist1, dist2 = distChamfer(array1, array2)
+    return (torch.mean(dist1) + torch.mean(dist2)) * 1000
+
+
+def F1Score(array1, array2, threshold=0.001):
+    """completion_trainer/Latent_SDE_Trainer.py:47-53: per-cloud F1 of the two nearest-neighbour precisions at `threshold`
+    (squared distance); 0/0 -> 0.  Returns (fscore, precision_1, precision_2)."""
+    dist1, dist2 = distChamfer(array1, array2)
+    precision_1 = torch.mean((dist1 < threshold).float(), dim=1)
+    precision_2 = torch.mean((dist2 < threshold).float(), dim=1)
+    fscore = 2 * precision_1 * precision_2 / (precision_1 + precision_2)
+    fscore[torch.isnan(fscore)] = 0
+    return fscore, precision_1, precision_2
+
+
 def emd_approx(sample, ref):
     """emd_approx_cuda (:40-46): approximate-matching cost / n, one value per cloud pair (sample[b], ref[b])."""
     B, N, N_ref = sample.size(0), sample.size(1), ref.size(1)

@@ -194,6 +194,46 @@ class Trainer:
         self.compressor.init()
 
 
+class CompletionTrainer(Trainer):
+    """The sampling half of completion_trainer/Latent_SDE_Trainer.py (ShapeNet-ViPC completion, BASELINE configs[4]):
+    `sample(num_samples, condition={'img': views, 'pts': partial})` runs the score model's ConditionNet once per call
+    (:150-151; needs cfg.score.condition = True), samples image/partial-cloud conditioned latents and returns the decoded
+    clouds only (:168); `valsample` is the evaluation loop of :170-215 without the dataset and the renderer."""
+
+    @torch.no_grad()
+    def sample(self, num_samples, num_points=None, label=None, condition=None, **kw):
+        if isinstance(condition, dict):
+            if not hasattr(self.model, "c_net"):
+                raise ValueError("a raw condition dict needs cfg.score.condition=True (ConditionNet, score.py:64-65)")
+            condition = self.model.c_net({k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in condition.items()})
+        return super().sample(num_samples, num_points=num_points, label=label, condition=condition, **kw)[0]
+
+    @torch.no_grad()
+    def valsample(self, test_loader, vis=False, full=False):
+        """test_loader yields (views (B,3,H,W), pc (B,N,3), pc_part (B,Np,3)); both clouds are reduced to 2048 points by
+        farthest point sampling (:181-184), the partial cloud + views condition the sampler, and the running
+        L2_ChamferEval_1000 / F1Score over everything sampled so far are reported as upstream (:197-201).
+        Returns {'cd', 'f1', 'rate', 'samples', 'refs'}."""
+        from . import ops
+        from .metrics import F1Score, L2_ChamferEval_1000
+        self.model.eval(); self.compressor.eval()
+        all_ref, all_smp, use_time = [], [], 0.
+        for views, pc, pc_part in test_loader:
+            pc, pc_part = pc.to(self.device).float().contiguous(), pc_part.to(self.device).float().contiguous()
+            ref_pts = ops.gather_rows(pc, ops.fps(pc, min(2048, pc.shape[1])))
+            part = ops.gather_rows(pc_part, ops.fps(pc_part, min(2048, pc_part.shape[1])))
+            torch.cuda.synchronize()
+            t0 = time.time()
+            smp = self.sample(num_samples=ref_pts.size(0), condition={"img": views.float(), "pts": part})
+            torch.cuda.synchronize()
+            use_time += time.time() - t0
+            all_smp.append(smp); all_ref.append(ref_pts)
+        smp, ref = torch.cat(all_smp, 0), torch.cat(all_ref, 0)
+        cd = L2_ChamferEval_1000(smp, ref)
+        f1, _, _ = F1Score(smp, ref)
+        return {"cd": float(cd), "f1": float(f1.mean()), "rate": smp.shape[0] / max(use_time, 1e-9), "samples": smp, "refs": ref}
+
+
 def _rows(t, lo, hi, per):
     """Rows [lo,hi) of a full-batch tensor, zero-padded to `per` rows (last rank when B % world != 0)."""
     part = t[lo:min(hi, t.shape[0])]

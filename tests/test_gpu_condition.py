@@ -85,3 +85,40 @@ def test_score_with_raw_condition_dict_vs_oracle(tiny_cfg):
     p1, e1 = tr.sample(B, condition=cond, x0=x0, seed=5)
     p2, e2 = tr.sample(B, condition=score.c_net(cond), x0=x0, seed=5)
     assert torch.equal(e1, e2) and torch.equal(p1, p2)
+
+
+def test_completion_trainer_sample_and_valsample(tiny_cfg):
+    """completion_trainer/Latent_SDE_Trainer.py:147-215: CompletionTrainer.sample(condition={'img','pts'}) returns the decoded
+    clouds only and equals Trainer.sample on ConditionNet's output; valsample reduces both clouds to <= 2048 points by FPS,
+    samples conditioned on (views, partial cloud) and reports L2_ChamferEval_1000 / F1Score as defined upstream (:41-53)."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.condition = True
+    torch.manual_seed(8)
+    score = ldt_amd.Score(cfg.score)
+    with torch.no_grad():
+        _randomize(score, 9)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    comp.init()
+    ct = ldt_amd.CompletionTrainer(cfg, score, comp, "cuda:0")
+    g = torch.Generator().manual_seed(2)
+    B, T = 2, cfg.score.z_scale
+    npts = cfg.data.tr_max_sample_points                          # (the reference's bmm distChamfer needs equal point counts)
+    views = torch.randn(B, 3, 64, 64, generator=g); pc = torch.randn(B, npts, 3, generator=g) * 0.3; part = pc[:, :npts // 2] + 0.01
+    x0 = torch.randn(B, T, cfg.score.z_dim, generator=g)
+    cond = {"img": views.cuda(), "pts": part.cuda()}
+    only_pts = ct.sample(B, condition=cond, x0=x0, seed=3)
+    both = ldt_amd.Trainer.sample(ct, B, condition=ct.model.c_net(cond), x0=x0, seed=3)
+    assert torch.is_tensor(only_pts) and torch.equal(only_pts, both[0])
+    res = ct.valsample([(views, pc, part), (views * 0.5, pc * 1.1, part)])
+    smp, ref = res["samples"], res["refs"]
+    assert smp.shape == (2 * B, npts, 3) and ref.shape == (2 * B, npts, 3) and res["rate"] > 0
+    dl, dr = O.dist_chamfer(smp.cpu(), ref.cpu())
+    cd_ref = float((dl.mean() + dr.mean()) * 1000)
+    p1, p2 = (dl < 0.001).float().mean(1), (dr < 0.001).float().mean(1)
+    f = 2 * p1 * p2 / (p1 + p2); f[torch.isnan(f)] = 0
+    assert abs(res["cd"] - cd_ref) <= 1e-4 * abs(cd_ref) and abs(res["f1"] - float(f.mean())) < 1e-6
+    from ldt_amd.metrics import F1Score
+    fs, q1, q2 = F1Score(ref, ref + 0.001)                       # identical clouds up to a 1e-3 shift: every point within threshold
+    assert torch.allclose(fs.cpu(), torch.ones(2 * B)) and torch.allclose(q1.cpu(), torch.ones(2 * B))
