@@ -428,13 +428,7 @@ template <int DH>
 static int launch_resident(const AttnArgs* a, hipStream_t s) {
     const int ntl = (a->Nk + 63) / 64;
     const size_t lds = (size_t)2 * ntl * 64 * DH * 2 + 4 * 32 * DH * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_resident_kernel<DH>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        if (e != hipSuccess) { ldt_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    LDT_ENSURE_LDS(&attn_fwd_resident_kernel<DH>, 81920, "attention");
     hipLaunchKernelGGL(attn_fwd_resident_kernel<DH>, dim3((unsigned)(a->B * a->H)), dim3(256), lds, s, *a, ntl);
     return ldt_check_launch("attn_fwd_resident");
 }

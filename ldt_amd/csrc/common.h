@@ -28,6 +28,23 @@ int ldt_check_launch(const char* what);   // hipGetLastError -> status (+ messag
         }                                     \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit once per (call site, device): thread-safe (sub-batch streams call the launchers from
+// several host threads) and per device (the attribute belongs to the device current at the call).
+#include <atomic>
+#define LDT_ENSURE_LDS(kernel_ptr, bytes, what)                                                                       \
+    do {                                                                                                              \
+        static std::atomic<unsigned long long> _lds_done{0};                                                          \
+        int _dev = 0;                                                                                                 \
+        (void)hipGetDevice(&_dev);                                                                                    \
+        const unsigned long long _bit = 1ull << (_dev & 63);                                                          \
+        if (!(_lds_done.load(std::memory_order_acquire) & _bit)) {                                                    \
+            const hipError_t _e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                      \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));           \
+            if (_e != hipSuccess) { ldt_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(_e)); return (int)_e; } \
+            _lds_done.fetch_or(_bit, std::memory_order_release);                                                      \
+        }                                                                                                             \
+    } while (0)
+
 __host__ __device__ static inline bool ldt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -333,26 +333,14 @@ __global__ __launch_bounds__(256, 2) void ln_linear_kernel(const LnLinArgs a) {
 
 template <int C>
 int launch_ln_linear(const LnLinArgs* a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear_kernel<C>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C>::LDS);
-        if (e != hipSuccess) { ldt_set_error("ln_linear: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    LDT_ENSURE_LDS(&ln_linear_kernel<C>, MlpCfg<C>::LDS, "ln_linear");
     hipLaunchKernelGGL(ln_linear_kernel<C>, dim3((unsigned)((a->M + 127) / 128)), dim3(256), MlpCfg<C>::LDS, st, *a);
     return ldt_check_launch("ln_linear");
 }
 
 template <int C, bool GATED>
 int launch_mlp(const MlpArgs* a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_resid_kernel<C, GATED>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C>::LDS);
-        if (e != hipSuccess) { ldt_set_error("ln_mlp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    LDT_ENSURE_LDS((&ln_mlp_resid_kernel<C, GATED>), MlpCfg<C>::LDS, "ln_mlp");
     const long blocks = (a->M + 127) / 128;
     hipLaunchKernelGGL((ln_mlp_resid_kernel<C, GATED>), dim3((unsigned)blocks), dim3(256), MlpCfg<C>::LDS, st, *a);
     return ldt_check_launch("ln_mlp_resid");

@@ -690,22 +690,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 }
 
 // rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
-static int g_group_m = -1;
-extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m = gm; return LDT_OK; }
+static std::atomic<int> g_group_m{-1};
+extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LDT_OK; }
 
 template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
-    if (g_group_m < 0) g_group_m = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : 1;
+    static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : 1;
+    const int gm_dbg = g_group_m.load();
     GemmArgs a_copy = *a_in;
-    a_copy.group_m = g_group_m;
+    a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env;
     const GemmArgs* a = &a_copy;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_nt_256_kernel<EPI, FOLD>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
-        if (e != hipSuccess) { ldt_set_error("gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256");
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;

@@ -166,12 +166,7 @@ int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, i
     LDT_REQUIRE(pairwise || S == R, LDT_ESHAPE, "emd_approx: batched mode pairs cloud b with cloud b (S=%d != R=%d)", S, R);
     const size_t lds = (size_t)(n + m) * (sizeof(float4) + sizeof(float));
     LDT_REQUIRE(lds <= 150 * 1024, LDT_ESHAPE, "emd_approx: n + m = %d points exceed the LDS-resident limit (7680)", n + m);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(emd_approx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { ldt_set_error("emd_approx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    LDT_ENSURE_LDS(emd_approx_kernel, 150 * 1024, "emd_approx");
     const long npairs = pairwise ? (long)S * R : S;
     const int grid = (int)(npairs < 4096 ? npairs : 4096);
     hipLaunchKernelGGL(emd_approx_kernel, dim3(grid), dim3(1024), lds, st, x, y, S, R, n, m, pairwise, out);

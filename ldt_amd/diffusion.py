@@ -171,8 +171,8 @@ class DiffusionVPSDE:
         # initial sample: CPU generator then copy, exactly like the reference (:237)
         x = torch.randn((num_samples,) + tuple(shape)) if x0 is None else x0
         x = x.to(dev, torch.float32).contiguous().clone()
-        if seed is None:                                       # Philox key from the (seedable) CPU generator
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if seed is None:                                       # Philox key from the (seedable) CPU generator; not drawn (the
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0   # reference's stream is kept) when noise is injected
         ncs = corrector_steps if corrector is not None else 0  # noise draws per step: 1 predictor + ncs corrector
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()

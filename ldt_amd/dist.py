@@ -29,3 +29,20 @@ def all_gather_rows(local, num_samples):
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
     return out[:num_samples]
+
+
+def check_same_draws(x0, seed, device):
+    """Every rank draws the full-batch x0 and the Philox key from its own CPU generator and keeps its rows, so the result
+    is independent of the world size only if the generators were seeded identically (the reference's common_init,
+    tools/utils.py:269-276).  One 16-byte all-gather of (key, bit pattern of sum(x0)) — control plane, not the data path —
+    turns a silent mismatch into an error."""
+    rank, ws = world()
+    if ws == 1:
+        return
+    dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([0 if seed is None else int(seed), int(x0.double().sum().view(torch.int64).item())], dtype=torch.int64, device=dev)
+    allv = torch.empty((ws, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allv, mine)
+    if not bool((allv == allv[0]).all()):
+        raise RuntimeError("Trainer.sample: ranks drew different x0 / noise keys (rank %d: %s; rank 0: %s) — seed the CPU generator "
+                           "identically on every rank (torch.manual_seed) or pass x0= / seed=" % (rank, mine.tolist(), allv[0].tolist()))

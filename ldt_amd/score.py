@@ -164,7 +164,9 @@ class Score(nn.Module):
 
     def project_condition(self, pts_cond):
         """pts_cond (B, hidden, S) channels-first (what ConditionNet returns, score.py:41-44) -> per even block the
-        K|V rows [B*S, 2*hidden] bf16.  Step-invariant: computed once and cached per condition tensor."""
+        K|V rows [B*S, 2*hidden] bf16.  Step-invariant: computed once and cached per condition tensor.  The cache entry
+        holds a reference to that tensor, so its storage cannot be freed and handed to the next batch's condition (same
+        address, same version) while the entry is alive."""
         key = (pts_cond.data_ptr(), pts_cond._version, tuple(pts_cond.shape))
         self.packed()
         if key not in self._cond_cache:
@@ -176,8 +178,8 @@ class Score(nn.Module):
             for l in range(0, self.num_blocks, 2):                                  # score.py:149: idx % 2 == 0
                 _, _, wkv, bkv = self._cross_panels(l)
                 kv[l] = ops.gemm_bf16(yb, wkv, bkv, EPI_BF16)
-            self._cond_cache = {key: (kv, S)}
-        return self._cond_cache[key]
+            self._cond_cache = {key: (kv, S, pts_cond)}
+        return self._cond_cache[key][:2]
 
     def _workspace(self, B, T, slot=0):
         """Activation buffers of a (B, T) batch; `slot` separates the sub-batches that run concurrently on their own streams."""

@@ -90,8 +90,10 @@ class Trainer:
             # every rank draws the FULL-batch x0 from its (identically seeded) CPU generator, then keeps its rows
             if x0 is None:
                 x0 = torch.randn((num_samples,) + shape)
-            if seed is None:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            if seed is None and noise is None and self.sample_mode == "discrete":
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # Philox key (only when device noise will be drawn)
+            if ws > 1:
+                ldist.check_same_draws(x0, seed, self.device)            # world-size invariance needs identical CPU generators
             x0_loc = _rows(x0, lo, hi, per)
             noise_loc = None if noise is None else _rows(noise.transpose(0, 1), lo, hi, per).transpose(0, 1)
             if ws > 1:                                   # per-sample conditioning follows its samples to their rank
@@ -209,15 +211,21 @@ class CompletionTrainer(Trainer):
         return super().sample(num_samples, num_points=num_points, label=label, condition=condition, **kw)[0]
 
     @torch.no_grad()
-    def valsample(self, test_loader, vis=False, full=False):
+    def valsample(self, test_loader, vis=False, full=False, save_npy=None):
         """test_loader yields (views (B,3,H,W), pc (B,N,3), pc_part (B,Np,3)); both clouds are reduced to 2048 points by
-        farthest point sampling (:181-184), the partial cloud + views condition the sampler, and the running
-        L2_ChamferEval_1000 / F1Score over everything sampled so far are reported as upstream (:197-201).
-        Returns {'cd', 'f1', 'rate', 'samples', 'refs'}."""
+        farthest point sampling (:181-184), the partial cloud + views condition the sampler, and L2_ChamferEval_1000 /
+        F1Score over everything sampled are reported as upstream (:197-201).  full=False stops once more than 1000 shapes
+        are accumulated (:203-205).  The `part_ep / smp_ep / ref_ep<epoch>.npy` dumps of :216-227 are written when
+        cfg.log.save_path is set (save_npy=None) or on request (save_npy=True).  vis=True (mitsuba rendering, :208-213) is
+        out of scope and raises.  Returns {'cd', 'f1', 'f1score', 'rate', 'samples', 'refs', 'parts'}."""
+        import os
+        import numpy as np
         from . import ops
         from .metrics import F1Score, L2_ChamferEval_1000
+        if vis:
+            raise NotImplementedError("valsample(vis=True): mitsuba rendering (tools/vis_utils.py) is not on this path")
         self.model.eval(); self.compressor.eval()
-        all_ref, all_smp, use_time = [], [], 0.
+        all_ref, all_smp, all_part, use_time, count = [], [], [], 0., 0
         for views, pc, pc_part in test_loader:
             pc, pc_part = pc.to(self.device).float().contiguous(), pc_part.to(self.device).float().contiguous()
             ref_pts = ops.gather_rows(pc, ops.fps(pc, min(2048, pc.shape[1])))
@@ -227,11 +235,20 @@ class CompletionTrainer(Trainer):
             smp = self.sample(num_samples=ref_pts.size(0), condition={"img": views.float(), "pts": part})
             torch.cuda.synchronize()
             use_time += time.time() - t0
-            all_smp.append(smp); all_ref.append(ref_pts)
-        smp, ref = torch.cat(all_smp, 0), torch.cat(all_ref, 0)
+            all_smp.append(smp); all_ref.append(ref_pts); all_part.append(part)
+            count += smp.shape[0]
+            if not full and count > 1000:                                             # :203-205
+                break
+        smp, ref, part = torch.cat(all_smp, 0), torch.cat(all_ref, 0), torch.cat(all_part, 0)
         cd = L2_ChamferEval_1000(smp, ref)
         f1, _, _ = F1Score(smp, ref)
-        return {"cd": float(cd), "f1": float(f1.mean()), "rate": smp.shape[0] / max(use_time, 1e-9), "samples": smp, "refs": ref}
+        path = getattr(self.cfg.log, "save_path", "")
+        if save_npy or (save_npy is None and path):
+            for tag, t in (("part", part), ("smp", smp), ("ref", ref)):
+                np.save(os.path.join(path, "%s_ep%d.npy" % (tag, self.epoch)), t.detach().cpu().numpy())
+        print("Validation Sample (unit) Epoch:%d " % self.epoch, {"cd": float(cd), "f1score": float(f1.mean())})
+        return {"cd": float(cd), "f1": float(f1.mean()), "f1score": float(f1.mean()), "rate": smp.shape[0] / max(use_time, 1e-9),
+                "samples": smp, "refs": ref, "parts": part}
 
 
 def _rows(t, lo, hi, per):
