@@ -122,3 +122,40 @@ def test_completion_trainer_sample_and_valsample(tiny_cfg):
     from ldt_amd.metrics import F1Score
     fs, q1, q2 = F1Score(ref, ref + 0.001)                       # identical clouds up to a 1e-3 shift: every point within threshold
     assert torch.allclose(fs.cpu(), torch.ones(2 * B)) and torch.allclose(q1.cpu(), torch.ones(2 * B))
+
+
+def test_condition_cache_not_reused_across_batches(tiny_cfg):
+    """Two sample() calls with DIFFERENT partial clouds: ConditionNet's output of the second call lands in the storage the
+    caching allocator recycled from the first (same address, shape, version 0); the step-invariant cross-attention K/V
+    must be rebuilt, not served from the first batch's cache entry.  Checked against a model that never saw batch 1."""
+    import ldt_amd
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.condition = True
+
+    def make():
+        torch.manual_seed(8)
+        score = ldt_amd.Score(cfg.score)
+        with torch.no_grad():
+            _randomize(score, 9)
+        comp = ldt_amd.Compressor(cfg.compressor)
+        comp.init()
+        return ldt_amd.CompletionTrainer(cfg, score, comp, "cuda:0")
+
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, cfg.score.z_scale
+    views = torch.randn(B, 3, 64, 64, generator=g).cuda()
+    part1 = (torch.randn(B, 96, 3, generator=g) * 0.3).cuda()
+    part2 = (torch.randn(B, 96, 3, generator=g) * 0.3).cuda()
+    x0 = torch.randn(B, T, cfg.score.z_dim, generator=g)
+    ct = make()
+    s1 = ct.sample(B, condition={"img": views, "pts": part1}, x0=x0, seed=3)
+    s2 = ct.sample(B, condition={"img": views, "pts": part2}, x0=x0, seed=3)
+    fresh = make().sample(B, condition={"img": views, "pts": part2}, x0=x0, seed=3)
+    assert torch.equal(s2, fresh)
+    assert not torch.equal(s1, s2)
+    # the same holds for repeated Score.forward calls on ConditionNet outputs
+    xs, t = torch.randn(B, T, cfg.score.z_dim, generator=g).cuda(), torch.tensor([0.6, 0.3]).cuda()
+    m = ct.model
+    m(xs, t, condition=m.c_net({"img": views, "pts": part1}))
+    o2 = m(xs, t, condition=m.c_net({"img": views, "pts": part2}))
+    assert torch.equal(o2, make().model(xs, t, condition={"img": views, "pts": part2}))
