@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 7
+#define LDT_ABI_VERSION 8
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -131,6 +131,26 @@ int ldt_sampler_step(const float* x, const float* params, const float* noise, in
                      int64_t n, int64_t elem_offset, uint64_t seed,
                      int32_t philox_mul, int32_t philox_add, void* stream);
 int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int32_t step, uint64_t seed, void* stream);
+
+/* ---- LangevinCorrector (diffusion/diffusion_continuous.py:193-210) --------------------------------------
+ * ldt_batch_norm_sum: *sum_out = sum_b ||x[b,:]||_2 over B samples of per_sample fp32 values each — the numerator of
+ *   torch.norm(v.reshape(B,-1), dim=-1).mean() (:204-205); norms_scratch[B] receives the per-sample norms.
+ *   Fixed reduction order, no atomics.  When the batch is sharded the caller all-reduces the two sums.
+ * ldt_langevin_coef: sums = {sum_b ||params_b||, sum_b ||z_b||} over n_total samples -> coef_out[4] = {1, -step/std,
+ *   sqrt(2 step), 0}, step = (snr * noise_norm / grad_norm)^2 * 2 with grad = -params/std (:206, alpha = 1), the row
+ *   ldt_sampler_step(mode 1) applies: x_mean = x + step*grad, x = x_mean + sqrt(2 step) z (:207-208). */
+int ldt_batch_norm_sum(const float* x, int32_t B, int64_t per_sample, float* norms_scratch, float* sum_out, void* stream);
+int ldt_langevin_coef(const float* sums, int32_t n_total, float snr, float std_t, float* coef_out, void* stream);
+
+/* ---- PNDM (diffusion/diffusion_continuous.py:260-316) -----------------------------------------------------
+ * ldt_pndm_transfer: out = x + d * (p*x - q*et), the transfer() of :263-274 with the batch-uniform schedule scalars
+ *   d = at_next - at, p = 1/(sqrt(at)(sqrt(at)+sqrt(at_next))), q = 1/(sqrt(at)(sqrt((1-at_next)at)+sqrt((1-at)at_next)))
+ *   formed by the host in fp32; reference op order, no FMA contraction.  out may alias x.
+ * ldt_lincomb4: out = s * (((c0 a0 + c1 a1) + c2 a2) + c3 a3): the Runge-Kutta average of :291 and the 4-step
+ *   multistep combination of :300. */
+int ldt_pndm_transfer(const float* x, const float* et, float d, float p, float q, float* out, int64_t n, void* stream);
+int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float* a3, float c0, float c1, float c2, float c3,
+                 float s, float* out, int64_t n, void* stream);
 
 /* ---- Compressor encoder front end (model/Compressor/layers.py:65-112, 288-319; Network.py:26-29,76,86-107) ----
  * Clouds are fp32 [B][n][3]; index outputs are int32.

@@ -1,0 +1,126 @@
+// Device ops of the remaining samplers around the Score forward: LangevinCorrector (diffusion/diffusion_continuous.py:193-210)
+// and PNDM (:260-316).  All are HBM-streaming passes over the latents [B][tokens*z] fp32 — a few MB, far below the
+// Score forward they sit next to — written for determinism (fixed reduction order, no atomics) rather than speed.
+#include "../../include/ldt_hip.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// per-sample L2 norms (torch.norm(v.reshape(B, -1), dim=-1), :204-205): one 256-thread workgroup per sample,
+// 16-B loads, wave shuffle + LDS tree in a fixed order.
+__global__ __launch_bounds__(256) void batch_norms_kernel(const float* __restrict__ x, long per, float* __restrict__ out) {
+    const float* row = x + (long)blockIdx.x * per;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < per / 4; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
+        acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+}
+// sum over the batch of the per-sample norms (the numerator of .mean()): one wave, fixed order
+__global__ __launch_bounds__(64) void norm_sum_kernel(const float* __restrict__ norms, int B, float* __restrict__ sum_out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 64) acc += norms[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *sum_out = acc;
+}
+
+extern "C" int ldt_batch_norm_sum(const float* x, int32_t B, int64_t per_sample, float* norms_scratch, float* sum_out, void* stream) {
+    LDT_REQUIRE(x && norms_scratch && sum_out, LDT_EARG, "batch_norm_sum: null pointer");
+    LDT_REQUIRE(B > 0 && per_sample > 0 && per_sample % 4 == 0 && ldt_aligned16(x), LDT_ESHAPE,
+                "batch_norm_sum: per_sample=%ld must be a multiple of 4, x 16-byte aligned", (long)per_sample);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(batch_norms_kernel, dim3((unsigned)B), dim3(256), 0, s, x, (long)per_sample, norms_scratch);
+    hipLaunchKernelGGL(norm_sum_kernel, dim3(1), dim3(64), 0, s, norms_scratch, B, sum_out);
+    return ldt_check_launch("batch_norm_sum");
+}
+
+// Langevin step size -> one coefficient row {A, B, C, 0} for ldt_sampler_step(mode 1) (x_mean = A x + B params, x = x_mean + C z):
+//   grad = score = -params / std  =>  grad_norm = mean_b ||params_b|| / std ;  noise_norm = mean_b ||z_b||
+//   step_size = (snr * noise_norm / grad_norm)^2 * 2 * alpha,  alpha = 1 (the reference's class test at :195 is never true)
+//   x_mean = x + step_size * grad = x - (step_size / std) params ;  x = x_mean + sqrt(2 step_size) z
+// sums[0] = sum_b ||params_b||, sums[1] = sum_b ||z_b|| over the WHOLE batch (all-reduced by the caller when sharded).
+__global__ void langevin_coef_kernel(const float* __restrict__ sums, int n_total, float snr, float std_t, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float grad_norm = (sums[0] / (float)n_total) / std_t;
+    const float noise_norm = sums[1] / (float)n_total;
+    const float r = snr * noise_norm / grad_norm;
+    const float step = r * r * 2.0f;
+    coef[0] = 1.0f; coef[1] = -step / std_t; coef[2] = sqrtf(step * 2.0f); coef[3] = 0.f;
+}
+extern "C" int ldt_langevin_coef(const float* sums, int32_t n_total, float snr, float std_t, float* coef_out, void* stream) {
+    LDT_REQUIRE(sums && coef_out && n_total > 0 && std_t > 0.f, LDT_EARG, "langevin_coef: bad argument");
+    hipLaunchKernelGGL(langevin_coef_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sums, n_total, snr, std_t, coef_out);
+    return ldt_check_launch("langevin_coef");
+}
+
+// ------------------------------------------------------------------------------------------------
+// PNDM (:260-316).  transfer(): x_next = x + d * (p * x - q * et) with the three schedule scalars of :267-271 formed by
+// the host in fp32 (they are batch-uniform: every sample is at the same t); the element-wise op order is the reference's.
+__global__ __launch_bounds__(256) void pndm_transfer_kernel(const float* __restrict__ x, const float* __restrict__ et, float d, float p,
+                                                            float q, float* __restrict__ out, long nvec) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(et + 4 * i);
+        f32x4 o;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = p * xv[j];
+                const float b = q * ev[j];
+                const float dl = d * (a - b);
+                o[j] = xv[j] + dl;
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = o;
+    }
+}
+extern "C" int ldt_pndm_transfer(const float* x, const float* et, float d, float p, float q, float* out, int64_t n, void* stream) {
+    LDT_REQUIRE(x && et && out, LDT_EARG, "pndm_transfer: null pointer");
+    LDT_REQUIRE(n > 0 && n % 4 == 0 && ldt_aligned16(x) && ldt_aligned16(et) && ldt_aligned16(out), LDT_EALIGN,
+                "pndm_transfer: n %% 4 and 16-byte aligned buffers");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pndm_transfer_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, et, d, p, q, out, n / 4);
+    return ldt_check_launch("pndm_transfer");
+}
+
+// out = s * (((c0 a0 + c1 a1) + c2 a2) + c3 a3): the Runge-Kutta average (1/6)(e1 + 2 e2 + 2 e3 + e4) (:291) and the
+// 4-step linear multistep combination (1/24)(55 e[-1] - 59 e[-2] + 37 e[-3] - 9 e[-4]) (:300), left to right as torch does.
+struct Lin4Args { const float* a[4]; float c[4]; float s; float* out; long nvec; };
+__global__ __launch_bounds__(256) void lincomb4_kernel(const Lin4Args g) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < g.nvec; i += (long)gridDim.x * 256) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(g.a[k] + 4 * i);
+        f32x4 o;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = g.c[0] * v[0][j];
+                const float t1 = g.c[1] * v[1][j];
+                const float t2 = g.c[2] * v[2][j];
+                const float t3 = g.c[3] * v[3][j];
+                const float acc = ((t0 + t1) + t2) + t3;
+                o[j] = g.s * acc;
+            }
+        }
+        *reinterpret_cast<f32x4*>(g.out + 4 * i) = o;
+    }
+}
+extern "C" int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float* a3, float c0, float c1, float c2, float c3,
+                            float s, float* out, int64_t n, void* stream) {
+    LDT_REQUIRE(a0 && a1 && a2 && a3 && out, LDT_EARG, "lincomb4: null pointer");
+    LDT_REQUIRE(n > 0 && n % 4 == 0 && ldt_aligned16(a0) && ldt_aligned16(a1) && ldt_aligned16(a2) && ldt_aligned16(a3) && ldt_aligned16(out),
+                LDT_EALIGN, "lincomb4: n %% 4 and 16-byte aligned buffers");
+    Lin4Args g{{a0, a1, a2, a3}, {c0, c1, c2, c3}, s, out, n / 4};
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+    return ldt_check_launch("lincomb4");
+}

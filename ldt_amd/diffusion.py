@@ -149,21 +149,26 @@ class DiffusionVPSDE:
     @torch.no_grad()
     def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,
                         probability_flow, denoise, snr, device, condition=None, label=None, print_steps=None,
-                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None, streams=None):
+                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None, streams=None, global_batch=None):
         """Reverse-SDE predictor(-corrector) sampling, diffusion_continuous.py:133-338.
 
-        corrector: None or 'ancestral' (AncestralCorrector :212-229; alpha = 1 by the reference's quirk Q11).
-        'langevin' (:193-210) and predictor 'pndm' (:260-316) multiply a (B,1) factor into (B,tokens,z) latents and
-        raise a broadcasting error in the reference itself unless B == tokens; they are rejected here too.
+        corrector: None, 'ancestral' (AncestralCorrector :212-229; alpha = 1 by the reference's quirk Q11) or 'langevin'
+        (LangevinCorrector :193-210).  predictor 'pndm' runs PNDM (:260-316; corrector / noise are not used by it).
+        Langevin and PNDM multiply a (B,1) factor into (B,tokens,z) latents: the reference only runs them when B == 1 or
+        B == tokens (the factor is batch-uniform, so the result is well defined then) and raises torch's broadcasting
+        error otherwise; the same rule is applied here to the GLOBAL batch (`global_batch`, default num_samples).
+        Langevin's step size uses batch means of norms — under a sharded batch the two norm sums are all-reduced (the one
+        cross-sample quantity on the path); everything else stays per rank.
         print_steps: the trajectory dump of :239-257 (returns the list of tensors)."""
-        if corrector not in (None, "ancestral"):
-            if corrector == "langevin":
-                raise NotImplementedError("LangevinCorrector: the reference broadcasts step_size[:, None] against "
-                                          "(B,tokens,z) latents (diffusion_continuous.py:208-209) and fails unless B == tokens")
+        if corrector not in (None, "ancestral", "langevin"):
             raise NotImplementedError("corrector not Implemented")           # diffusion_continuous.py:335
+        gb = num_samples if global_batch is None else int(global_batch)
+        if predictor == "pndm" or corrector == "langevin":
+            if not (gb == 1 or gb == shape[0]) or shape[0] == 1 and gb != 1:
+                raise RuntimeError("The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1"
+                                   % (gb, shape[0]))                         # what torch raises at :208 / :269
         if predictor == "pndm":
-            raise NotImplementedError("PNDM: the reference's transfer() views alphas as (B,1) against (B,tokens,z) latents "
-                                      "(diffusion_continuous.py:267-271) and fails unless B == tokens")
+            return self._sample_pndm(score_fn, num_samples, shape, time_eps, device, condition, label, x0)
         ts, coef, mode = self.step_table(N, predictor, time_eps, probability_flow)
         dev = torch.device(device)
         if dev.type != "cuda":
@@ -270,10 +275,17 @@ class DiffusionVPSDE:
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)
-        if corrector is not None:                              # folded AncestralCorrector: x_mean = x - 2 snr^2 std params,
+        if corrector == "ancestral":                           # folded AncestralCorrector: x_mean = x - 2 snr^2 std params,
             std = self.std(ts).double()                        # x = x_mean + 2 snr std z   (score = -params / std)
             ccoef = torch.stack([torch.ones_like(std), -2.0 * snr * snr * std, 2.0 * snr * std, torch.zeros_like(std)], 1)
             ccoef_d = ccoef.float().contiguous().to(dev)
+        elif corrector == "langevin":                          # step size from batch-mean norms, formed on the device per draw
+            std_host = self.std(ts)
+            lv_coef = torch.empty(4, dtype=torch.float32, device=dev)
+            lv_sums = torch.empty(2, dtype=torch.float32, device=dev)
+            lv_norms = torch.empty(num_samples, dtype=torch.float32, device=dev)
+            per = int(np.prod(shape))
+            n_valid = max(0, min(num_samples, gb - int(sample_offset)))
         out_list, every = None, None
         if print_steps is not None:
             out_list, every = [x.clone()], (N - 1) // (print_steps - 2)
@@ -286,17 +298,97 @@ class DiffusionVPSDE:
             if record is not None:
                 record.append((x, params, x_mean.clone(), x_new))
             x = x_new
-            for j in range(ncs):                                                     # AncestralCorrector :212-229
+            for j in range(ncs):
                 _, params = score_fn(vec_t, x, label=label, condition=condition)
-                x = ops.sampler_step(x, params.contiguous(), ccoef_d, i, 1, noise=None if noise is None else noise[k + 1 + j],
-                                     x_mean_out=x_mean, elem_offset=elem_offset, seed=seed, philox_mul=1 + ncs,
-                                     philox_add=1 + j)
+                params = params.contiguous()
+                if corrector == "ancestral":                                         # AncestralCorrector :212-229
+                    x = ops.sampler_step(x, params, ccoef_d, i, 1, noise=None if noise is None else noise[k + 1 + j],
+                                         x_mean_out=x_mean, elem_offset=elem_offset, seed=seed, philox_mul=1 + ncs,
+                                         philox_add=1 + j)
+                    continue
+                # LangevinCorrector :193-210
+                z = noise[k + 1 + j] if noise is not None else \
+                    ops.philox_normal(x.shape, dev, seed, step=i * (1 + ncs) + 1 + j, elem_offset=elem_offset)
+                st = ops.stream_ptr()
+                if n_valid > 0:                                                      # (padding rows of the last rank do not count)
+                    check(lib().ldt_batch_norm_sum(params.data_ptr(), n_valid, per, lv_norms.data_ptr(), lv_sums.data_ptr(), st),
+                          "ldt_batch_norm_sum")
+                    check(lib().ldt_batch_norm_sum(z.data_ptr(), n_valid, per, lv_norms.data_ptr(), lv_sums[1:].data_ptr(), st),
+                          "ldt_batch_norm_sum")
+                else:
+                    lv_sums.zero_()
+                if global_batch is not None:                                         # sharded batch: the path's one cross-sample quantity
+                    from . import dist as ldist
+                    ldist.all_reduce_sum_(lv_sums)
+                check(lib().ldt_langevin_coef(lv_sums.data_ptr(), gb, float(snr), float(std_host[i]), lv_coef.data_ptr(), st),
+                      "ldt_langevin_coef")
+                x = ops.sampler_step(x, params, lv_coef, 0, 1, noise=z, x_mean_out=x_mean)
             if out_list is not None and (i + 1) % every == 0:
                 out_list.append(x_mean.clone())
         if out_list is not None:
             out_list.append((x_mean if denoise else x).clone())
             return out_list
         return x_mean if denoise else x
+
+
+    @torch.no_grad()
+    def _sample_pndm(self, score_fn, num_samples, shape, time_eps, device, condition, label, x0):
+        """PNDM (diffusion_continuous.py:260-316) around the HIP Score: the pseudo linear multistep sampler with three
+        Runge-Kutta warm-up steps (4 Score evaluations each), self.N steps over self.train_N training levels.  Every
+        sample sits at the same t, so the (B,1) schedule factors of transfer() (:267-271) are three scalars per call,
+        formed here in fp32 exactly as upstream; the element-wise updates are HIP kernels.  Index quirk kept: at the last
+        step `timesteps[t_next*2 - 1]` with t_next = 0 reads timesteps[-1] = 1.0 (:307)."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("sample_discrete: device %s — the HIP path has no CPU fallback" % (device,))
+        N, train_N = self.N, self.train_N
+        x = (torch.randn((num_samples,) + tuple(shape)) if x0 is None else x0).to(dev, torch.float32).contiguous().clone()
+        betas = torch.from_numpy(np.linspace(self.beta_start / train_N, self.beta_end / train_N, train_N,
+                                             dtype=np.float64)).to(torch.float32)                    # :310-313
+        alphas_cump = torch.cat((torch.ones(1), (1.0 - betas).cumprod(dim=0)))                     # :314-315 (train_N + 1)
+        timesteps = torch.linspace(time_eps, 1.0, N * 2)                                             # :262
+        st = ops.stream_ptr
+
+        def level(t):                                            # :264-265
+            return int((train_N * (t - time_eps) + 1).long())
+
+        def transfer(xx, t, t_next, et):                         # :263-274
+            at, at_next = alphas_cump[level(t)], alphas_cump[level(t_next)]
+            d = at_next - at
+            p = 1 / (at.sqrt() * (at.sqrt() + at_next.sqrt()))
+            q = 1 / (at.sqrt() * (((1 - at_next) * at).sqrt() + ((1 - at) * at_next).sqrt()))
+            out = torch.empty_like(xx)
+            check(lib().ldt_pndm_transfer(xx.data_ptr(), et.data_ptr(), float(d), float(p), float(q), out.data_ptr(), xx.numel(), st()),
+                  "ldt_pndm_transfer")
+            return out
+
+        def eps_at(t, xx):
+            vec_t = (torch.ones((num_samples,)) * t).to(dev)
+            return score_fn(vec_t, xx, condition=condition, label=label)[1].contiguous()
+
+        def lincomb(a, c, scale):
+            out = torch.empty_like(a[0])
+            check(lib().ldt_lincomb4(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), c[0], c[1], c[2], c[3],
+                                     scale, out.data_ptr(), out.numel(), st()), "ldt_lincomb4")
+            return out
+
+        ets = []
+        for idx in range(N, 0, -1):                              # :316-317
+            t_next = idx - 1
+            if len(ets) > 2:                                     # :296-300 linear multistep
+                ets.append(eps_at(timesteps[idx * 2 - 1], x))
+                ets = ets[-4:]
+                noise = lincomb((ets[-1], ets[-2], ets[-3], ets[-4]), (55.0, -59.0, 37.0, -9.0), 1 / 24)
+            else:                                                # :276-292 Runge-Kutta warm-up
+                t1, t2, t3 = timesteps[idx * 2 - 1], timesteps[int((idx + t_next) / 2 * 2) - 1], timesteps[int(t_next * 2) - 1]
+                e1 = eps_at(t1, x)
+                ets.append(e1)
+                e2 = eps_at(t2, transfer(x, t1, t2, e1))
+                e3 = eps_at(t2, transfer(x, t1, t2, e2))
+                e4 = eps_at(t3, transfer(x, t1, t3, e3))
+                noise = lincomb((e1, e2, e3, e4), (1.0, 2.0, 2.0, 1.0), 1 / 6)
+            x = transfer(x, timesteps[idx * 2 - 1], timesteps[t_next * 2 - 1], noise)               # :304-307
+        return x
 
 
 def _fused_model(score_fn):

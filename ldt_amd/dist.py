@@ -46,3 +46,18 @@ def check_same_draws(x0, seed, device):
     if not bool((allv == allv[0]).all()):
         raise RuntimeError("Trainer.sample: ranks drew different x0 / noise keys (rank %d: %s; rank 0: %s) — seed the CPU generator "
                            "identically on every rank (torch.manual_seed) or pass x0= / seed=" % (rank, mine.tolist(), allv[0].tolist()))
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks of a small device tensor (LangevinCorrector's batch-mean norms — the only cross-sample
+    quantity on the sampling path, diffusion_continuous.py:204-205).  gloo (CPU tests) reduces a host copy."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    return t

@@ -115,7 +115,7 @@ class Trainer:
                                                device=self.device, num_samples=per,
                                                probability_flow=self.cfg.sde.probability_flow, snr=self.cfg.sde.snr,
                                                condition=condition, x0=x0_loc, noise=noise_loc, sample_offset=lo,
-                                               seed=seed, use_graph=use_graph)
+                                               seed=seed, use_graph=use_graph, global_batch=num_samples if ws > 1 else None)
             npts = self.num_points if num_points is None else num_points
             sample = self.compressor.sample((per, npts), given_eps=eps)
             if ws > 1:                                   # the single collective of the path

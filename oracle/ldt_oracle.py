@@ -220,9 +220,10 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
 
     x0 [B,T,z] is the initial N(0,1) draw (:237); `noises` are the randn_like draws in consumption order: one per
     predictor call (:160 etc.; the last one is drawn but unused when denoise, quirk Q8) followed by
-    `corrector_steps` per corrector call.  corrector: None or 'ancestral' (AncestralCorrector :212-229, alpha = 1
-    by quirk Q11).  LangevinCorrector (:193-210) and PNDM (:260-316) broadcast a (B,1) factor against (B,T,z)
-    latents and raise in the reference unless B == T, so they are not restated.
+    `corrector_steps` per corrector call.  corrector: None, 'ancestral' (AncestralCorrector :212-229, alpha = 1
+    by quirk Q11) or 'langevin' (LangevinCorrector :193-210: its (B,) step size is indexed [:, None] against
+    (B,T,z) latents, which broadcasts only when B == 1 or B == T — kept as is, torch raises otherwise).
+    PNDM (:260-316) is `sample_pndm` below.
     record: optional list that receives (x_in, params, x_mean, x_out) per predictor step.
     max_steps: stop after that many steps (bench.py's bounded CPU-baseline sample).
     print_steps: trajectory dump of :239-257 (returns the list)."""
@@ -283,6 +284,16 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
                 step_size = (snr * std) ** 2 * 2 * torch.ones_like(t)
                 x_mean = x + step_size[:, None, None] * grad
                 x = x_mean + zc * torch.sqrt(step_size * 2)[:, None, None]
+        elif corrector == "langevin":                               # :193-210 (alpha = ones_like(t): the class test at :195 is never true)
+            alpha = torch.ones_like(t)
+            for _ in range(corrector_steps):
+                grad, params = score_fn(t, x)
+                zc = next(it)
+                grad_norm = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
+                noise_norm = torch.norm(zc.reshape(zc.shape[0], -1), dim=-1).mean()
+                step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+                x_mean = x + step_size[:, None] * grad              # (B,1) against (B,T,z): B == 1 or B == T only
+                x = x_mean + torch.sqrt(step_size * 2)[:, None] * zc
         elif corrector is not None:
             raise NotImplementedError("corrector not Implemented")  # :335
         if print_steps is not None and (i + 1) % every == 0:
@@ -291,6 +302,49 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
         out_list.append(x_mean if denoise else x)
         return out_list
     return x_mean if denoise else x
+
+
+def sample_pndm(sde_cfg, score_fn, x0, time_eps):
+    """diffusion/diffusion_continuous.py:260-316 (predictor == "pndm"): pseudo linear multistep sampling over
+    sde_cfg.sample_N steps on sde_cfg.train_N training levels, three Runge-Kutta warm-up steps.  x0 [B,T,z] is the
+    initial draw (:309).  transfer() views the gathered alphas as (B,1) against (B,T,z) latents (:267-268): runs only
+    when B == 1 or B == T, as upstream.  The last step reads timesteps[-1] (t_next = 0 -> index -1, :307) — kept."""
+    N, train_N = sde_cfg.sample_N, sde_cfg.train_N
+    betas = torch.from_numpy(np.linspace(sde_cfg.beta_start / train_N, sde_cfg.beta_end / train_N, train_N,
+                                         dtype=np.float64)).to(torch.float32)       # :310-313
+    alphas_cump = torch.cat((torch.ones(1), (1.0 - betas).cumprod(dim=0)))          # :314-315
+    timesteps = torch.linspace(time_eps, 1.0, N * 2)                                 # :262
+    B = x0.shape[0]
+
+    def transfer(x, t, t_next, et):                                                  # :263-274
+        t = (train_N * (t - time_eps) + 1).long()
+        t_next = (train_N * (t_next - time_eps) + 1).long()
+        at = alphas_cump[t].view(-1, 1)
+        at_next = alphas_cump[t_next].view(-1, 1)
+        x_delta = (at_next - at) * ((1 / (at.sqrt() * (at.sqrt() + at_next.sqrt()))) * x - 1 / (at.sqrt() * (
+            ((1 - at_next) * at).sqrt() + ((1 - at) * at_next).sqrt())) * et)
+        return x + x_delta
+
+    def at_time(i):
+        return timesteps[i].view(-1).expand(B)
+
+    sample, ets = x0, []
+    for t in range(N, 0, -1):                                                        # :316-317
+        t_next = t - 1
+        if len(ets) > 2:                                                             # :296-300
+            _, e = score_fn(at_time(t * 2 - 1), sample)
+            ets.append(e)
+            noise = (1 / 24) * (55 * ets[-1] - 59 * ets[-2] + 37 * ets[-3] - 9 * ets[-4])
+        else:                                                                        # runge_kutta :276-292
+            t1, t2, t3 = at_time(t * 2 - 1), at_time(int((t + t_next) / 2 * 2) - 1), at_time(int(t_next * 2) - 1)
+            _, e1 = score_fn(t1, sample)
+            ets.append(e1)
+            _, e2 = score_fn(t2, transfer(sample, t1, t2, e1))
+            _, e3 = score_fn(t2, transfer(sample, t1, t2, e2))
+            _, e4 = score_fn(t3, transfer(sample, t1, t3, e3))
+            noise = (1 / 6) * (e1 + 2 * e2 + 2 * e3 + e4)
+        sample = transfer(sample, at_time(t * 2 - 1), at_time(t_next * 2 - 1), noise)   # :304-307
+    return sample
 
 
 # ----------------------------------------------------------------------------- Compressor: decode

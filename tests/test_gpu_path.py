@@ -205,11 +205,44 @@ def test_ancestral_corrector_and_print_steps_golden(env):
     o1 = tr.SDE.sample_discrete(corrector="ancestral", corrector_steps=1, x0=a["corr_x0"], seed=5, **kw)
     o2 = tr.SDE.sample_discrete(corrector="ancestral", corrector_steps=1, x0=a["corr_x0"], seed=5, **kw)
     assert torch.equal(o1, o2) and torch.isfinite(o1).all()
-    for bad in (dict(corrector="langevin", corrector_steps=1), dict(corrector="bogus", corrector_steps=1)):
-        with pytest.raises(NotImplementedError):
-            tr.SDE.sample_discrete(x0=a["corr_x0"], **bad, **kw)
     with pytest.raises(NotImplementedError):
+        tr.SDE.sample_discrete(x0=a["corr_x0"], corrector="bogus", corrector_steps=1, **kw)
+    # B = 2 is neither 1 nor tokens (8): Langevin / PNDM raise the reference's broadcasting error (:208, :269)
+    with pytest.raises(RuntimeError, match="must match the size of tensor"):
+        tr.SDE.sample_discrete(x0=a["corr_x0"], corrector="langevin", corrector_steps=1, **kw)
+    with pytest.raises(RuntimeError, match="must match the size of tensor"):
         tr.SDE.sample_discrete(**{**kw, "predictor": "pndm"}, corrector=None, corrector_steps=1, x0=a["corr_x0"])
+
+
+def test_langevin_corrector_and_pndm_golden(env):
+    """LangevinCorrector (diffusion_continuous.py:193-210) and PNDM (:260-316) vs outputs captured from the reference at
+    B == tokens == 8 and B == 1 (the only batch sizes its (B,1) factors broadcast for), recorded draws injected."""
+    import copy
+    import ldt_amd
+    a, _ = load_golden("sampler_langevin_pndm")
+    cfg = copy.deepcopy(env["cfg"])
+    cfg.sde.sample_N, cfg.sde.train_N = int(a["N"]), int(a["train_N"])
+    tr = ldt_amd.Trainer(cfg, env["score"], env["comp"], "cuda:0")
+    T, N = cfg.score.z_scale, cfg.sde.sample_N
+    kw = dict(score_fn=tr.score_fn, N=N, shape=(T, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=False,
+              denoise=True, snr=float(a["snr"]), device="cuda:0")
+    out = tr.SDE.sample_discrete(num_samples=T, predictor="eulermaruyama", corrector="langevin", corrector_steps=2,
+                                 x0=a["lv8_x0"], noise=a["lv8_noise"], **kw)
+    assert rel_mse(out.cpu(), a["lv8_out"]) < TOL_LATENT
+    out = tr.SDE.sample_discrete(num_samples=1, predictor="reversediffusion", corrector="langevin", corrector_steps=1,
+                                 x0=a["lv1_x0"], noise=a["lv1_noise"], **kw)
+    assert rel_mse(out.cpu(), a["lv1_out"]) < TOL_LATENT
+    for tag, B in (("pndm8", T), ("pndm1", 1)):
+        out = tr.SDE.sample_discrete(num_samples=B, predictor="pndm", corrector=None, corrector_steps=1, x0=a[tag + "_x0"], **kw)
+        assert rel_mse(out.cpu(), a[tag + "_out"]) < TOL_LATENT
+    # device-noise Langevin: seeded, reproducible, finite
+    o1 = tr.SDE.sample_discrete(num_samples=T, predictor="eulermaruyama", corrector="langevin", corrector_steps=1, x0=a["lv8_x0"], seed=11, **kw)
+    o2 = tr.SDE.sample_discrete(num_samples=T, predictor="eulermaruyama", corrector="langevin", corrector_steps=1, x0=a["lv8_x0"], seed=11, **kw)
+    assert torch.equal(o1, o2) and bool(torch.isfinite(o1).all())
+    # Trainer.sample dispatches on cfg.sde.predictor / corrector
+    cfg.sde.predictor, cfg.sde.corrector = "pndm", None
+    _, eps = tr.sample(T, x0=a["pndm8_x0"])
+    assert rel_mse(eps.cpu(), a["pndm8_out"]) < TOL_LATENT
 
 
 def test_decoder_golden(env):

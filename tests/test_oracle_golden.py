@@ -2,6 +2,7 @@
 imported upstream reference (oracle/gen_golden.py).  fp32 vs fp32 on the same CPU => the bar is
 round-off (rel-MSE <= 1e-10; tables bit-exact)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, rel_mse
@@ -144,6 +145,30 @@ def test_corrector_and_print_steps(tiny_cfg):
     traj = O.sample_discrete(sde, fn, a["print_x0"], list(a["print_noise"]), N, print_steps=5)
     assert len(traj) == a["print_out"].shape[0]
     assert rel_mse(torch.stack(traj), a["print_out"]) < 1e-8
+
+
+def test_langevin_and_pndm(tiny_cfg):
+    """LangevinCorrector (:193-210) and PNDM (:260-316) vs the reference at B == tokens == 8 and B == 1, plus its shape rule."""
+    import copy
+    a, _ = load_golden("sampler_langevin_pndm")
+    score_sd = load_golden("score_tiny")[1]["w"]
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.sde.sample_N, cfg.sde.train_N = int(a["N"]), int(a["train_N"])
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda x, tt: O.score_forward(score_sd, cfg.score, x, tt))
+    N, snr = cfg.sde.sample_N, float(a["snr"])
+    out = O.sample_discrete(sde, fn, a["lv8_x0"], list(a["lv8_noise"]), N, predictor="eulermaruyama", corrector="langevin",
+                            corrector_steps=2, snr=snr)
+    assert rel_mse(out, a["lv8_out"]) < 1e-8
+    out = O.sample_discrete(sde, fn, a["lv1_x0"], list(a["lv1_noise"]), N, predictor="reversediffusion", corrector="langevin",
+                            corrector_steps=1, snr=snr)
+    assert rel_mse(out, a["lv1_out"]) < 1e-8
+    for tag in ("pndm8", "pndm1"):
+        assert rel_mse(O.sample_pndm(cfg.sde, fn, a[tag + "_x0"], cfg.sde.sample_time_eps), a[tag + "_out"]) < 1e-8
+    with pytest.raises(RuntimeError, match="must match the size of tensor"):
+        O.sample_pndm(cfg.sde, fn, a["pndm8_x0"][:3], cfg.sde.sample_time_eps)
+    with pytest.raises(RuntimeError, match="must match the size of tensor"):
+        O.sample_discrete(sde, fn, a["lv8_x0"][:3], list(a["lv8_noise"][:, :3]), N, corrector="langevin", snr=snr)
 
 
 def test_decoder(tiny_cfg):
