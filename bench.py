@@ -10,11 +10,17 @@ Weights are seeded random-init (no checkpoints reachable), noise is device Philo
     python bench.py                                  # 1 GPU, K=2 timed sample() calls after W=1 warm-up
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line: metric shapes/sec (whole job), + `roofline` (dominant kernel, HIP-event timed
-inside this process) + `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+Rank 0 prints ONE JSON line: metric shapes/sec (whole job) and, at N=1,
+  roofline      dominant kernel of the Score forward, HIP-event timed inside this process (+ every kernel class in
+                `roofline_kernels`, each against the roofline that bounds it; `roofline_attention` = HBM GB/s)
+  cpu_baseline  config C1 EXACTLY (B=4, T=256, N=100, decode included) on the CPU oracle, x 1/10
+  parity        the same C1 run on the GPU with the same injected noise: per-step rel-MSE curve, final latents, Chamfer
+  extra         BASELINE configs[3] (Compressor B=1024), configs[4]'s per-GPU share (ViPC, B=32, T=32), shipped T=32
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +33,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0          # HBM3E spec, same table
-
 
 _T0 = time.time()
 
@@ -66,9 +71,10 @@ def parse():
     ap.add_argument("--tokens", type=int, default=256, help="latent tokens (BASELINE: 256; shipped YAML: 32)")
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--sde-steps", type=int, default=1000)
-    ap.add_argument("--cpu-steps", type=int, default=12, help="SDE steps of the bounded CPU-baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the C1 oracle run (cpu_baseline + parity)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] / T=32 blocks")
+    ap.add_argument("--budget-s", type=float, default=540.0, help="extras are skipped once the run is older than this")
     return ap.parse_args()
 
 
@@ -80,15 +86,35 @@ def score_flops_per_sample_step(cfg):
     return 2.0 * macs
 
 
+def csrc_sha():
+    """sha256 (16 hex) over the kernel sources: ties a PMC traffic measurement to the code it was collected on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ldt_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ldt_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE collected in separate passes; gfx950: FETCH_SIZE doubled, units KiB — MI355X_MICROARCH.md §HBM).
-    None when no measurement of this kernel at this workload has been committed."""
+    """(HBM bytes per launch of `symbol`, provenance) from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE in separate passes; gfx950: FETCH_SIZE doubled, units KiB — MI355X_MICROARCH.md §HBM;
+    reduced by tools/reduce_pmc.py).  The value is None when no measurement of this kernel exists OR the kernel
+    sources changed since it was collected (the provenance says which)."""
+    prov = {"file": "profiles/traffic.json", "current_csrc_sha": csrc_sha()}
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(symbol, {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(symbol)
     except (OSError, ValueError):
-        return None
+        e = None
+    if not e:
+        prov["status"] = "no measurement of this kernel committed"
+        return None, prov
+    prov.update(source=e.get("source"), collected_on_csrc_sha=e.get("csrc_sha"), note=e.get("note"))
+    if e.get("csrc_sha") != prov["current_csrc_sha"]:
+        prov["status"] = "stale: kernel sources changed since the PMC passes (value withheld: %d)" % e["hbm_bytes_per_launch"]
+        return None, prov
+    prov["status"] = "current"
+    return e["hbm_bytes_per_launch"], prov
 
 
 def roofline_pass(trainer, cfg, B, reps=3):
@@ -115,10 +141,16 @@ def roofline_pass(trainer, cfg, B, reps=3):
         for c in range(ncls):
             tot_ms[c] += ms[c]; tot_cnt[c] += cnt[c]
     M = B * T
-    flops = {"gemm_qkv": 2.0 * M * D * 3 * D, "gemm_gelu": 2.0 * M * D * F,
-             "gemm_resid": (2.0 * M * D * D + 2.0 * M * F * D) / 2.0,        # average of fc_o and mlp.out launches
+    # algorithmic work per launch: flops, and HBM bytes for the kernels whose roofline is HBM.
+    # fc_o at K = hidden is 177 flop/B (ridge ~310): bytes = Ob in (bf16) + x read + x write (fp32) + x(1+scale) out (bf16) + W
+    flops = {"gemm_qkv": 2.0 * M * D * 3 * D, "gemm_gelu": 2.0 * M * D * F, "gemm_o": 2.0 * M * D * D, "gemm_dn": 2.0 * M * F * D,
              "attention": 4.0 * M * T * D}
-    kernels = {}
+    xs_out = 2.0 * M * D if folded else 0.0
+    hbm_bytes = {"gemm_o": 2.0 * M * D + 8.0 * M * D + xs_out + 2.0 * D * D, "attention": 4.0 * M * D * 2,
+                 "ln_modulate": 4.0 * M * D + 2.0 * M * D}
+    fold_id = {"gemm_qkv": 2, "gemm_gelu": 2, "gemm_o": 1, "gemm_dn": 1}
+    epi_id = {"gemm_qkv": 1, "gemm_gelu": 2, "gemm_o": 4, "gemm_dn": 4}
+    kernels, roofs = {}, {}
     for c, name in enumerate(_lib.PROF_CLASSES):
         if tot_cnt[c] == 0:
             continue
@@ -126,51 +158,214 @@ def roofline_pass(trainer, cfg, B, reps=3):
         k = {"launches_per_forward": tot_cnt[c] // reps, "avg_ms": round(avg, 5), "ms_per_forward": round(tot_ms[c] / reps, 4)}
         if name in flops:
             k["tflops"] = round(flops[name] / (avg * 1e-3) / 1e12, 2)
+        if name in hbm_bytes:
+            k["gbps"] = round(hbm_bytes[name] / (avg * 1e-3) / 1e9, 1)
         kernels[name] = k
-    dom = max(("gemm_qkv", "gemm_gelu", "gemm_resid"), key=lambda n: kernels[n]["ms_per_forward"])
-    # symbols as rocprofv3 prints them: <epilogue id (1 BF16, 2 GELU_BF16, 4 RESID_F32), LN folding (0 none, 1 producer:
-    # also emits x(1+scale) + row statistics, 2 consumer: applies the LayerNorm in its epilogue)>
-    sym = {"gemm_qkv": "gemm_bf16_nt_256_kernel<1, %d>" % (2 if folded else 0), "gemm_gelu": "gemm_bf16_nt_256_kernel<2, %d>" % (2 if folded else 0),
-           "gemm_resid": "gemm_bf16_nt_256_kernel<4, %d>" % (1 if folded else 0)}[dom]
-    ach = kernels[dom]["tflops"]
-    roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(sym), "kernel": sym,
-            "flops_per_launch": flops[dom], "avg_launch_ms": kernels[dom]["avg_ms"], "ln_folding": folded}
-    a = kernels["attention"]
-    abytes = 4.0 * M * D * 2                                               # read Q,K,V + write O in bf16
-    gbs = abytes / (a["avg_ms"] * 1e-3) / 1e9
-    attn = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("attn_fwd_kernel<64, false>"), "kernel": "attn_fwd_kernel<64, false>",
-            "bytes_per_launch": abytes, "avg_launch_ms": a["avg_ms"]}
-    return roof, attn, kernels
+        sym = ("gemm_bf16_nt_256_kernel<%d, %d>" % (epi_id[name], fold_id[name] if folded else 0)) if name in epi_id else \
+            {"attention": "attn_fwd_kernel<64, false>", "ln_modulate": "ln_mod_vec_kernel<4>"}.get(name)
+        if sym is None:
+            continue
+        if name in hbm_bytes:                           # HBM-bound kernels: algorithmic bytes / time against 8 TB/s
+            r = {"bound": "hbm", "achieved": k["gbps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k["gbps"] / PEAK_HBM_GBS, 4),
+                 "bytes_per_launch": hbm_bytes[name]}
+        else:
+            r = {"bound": "mfma", "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "flops_per_launch": flops[name]}
+        tr_, prov = measured_traffic(sym)
+        r.update(traffic=tr_, traffic_source=prov, kernel=sym, op=name, avg_launch_ms=k["avg_ms"], ms_per_forward=k["ms_per_forward"],
+                 ln_folding=folded)
+        roofs[name] = r
+    dom = max((n for n in roofs if n.startswith("gemm_")), key=lambda n: kernels[n]["ms_per_forward"])
+    return roofs[dom], roofs, kernels
 
 
-def cpu_baseline(trainer, cfg, n_steps):
-    """The oracle (CPU restatement of the reference, kind "port") on this box's host cores: B=4 shapes,
-    same T and schedule, first `n_steps` of the 1000-step loop + one decode; per-step cost is
-    step-invariant, so shapes/s(1000 steps) = B / (1000 * t_step + t_decode)."""
+def rel_mse(a, b):
+    a, b = a.double(), b.double()
+    return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-300))
+
+
+def c1_baseline_and_parity(trainer, cfg_full):
+    """Config C1 EXACTLY (BASELINE.md §3 / SURVEY §8d): B=4, T=256, N=100 ancestral steps + decode.
+    The CPU oracle's wall time is the cpu_baseline (x 1/10 for N=1000: the loop body is step-invariant); its trajectory
+    is the parity reference for the SAME run on the GPU (same weights, same injected x0 / per-step noise)."""
+    import copy
+    import ldt_amd
     from oracle import ldt_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    B = 4
+    B, N = 4, 100
+    cfg = copy.deepcopy(cfg_full)
+    cfg.sde.sample_N = N
+    T, z = cfg.score.z_scale, cfg.score.z_dim
     sd_s = {k: v.detach().float().cpu() for k, v in trainer.model.state_dict().items()}
     sd_c = {k: v.detach().float().cpu() for k, v in trainer.compressor.state_dict().items()}
-    x0, noises = O.draw_noises(1234, B, cfg.score.z_scale, cfg.score.z_dim, n_steps)
-    sde = O.VPSDE(cfg.sde)
-    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd_s, cfg.score, x, t))
-    log("cpu baseline: %d threads, B=%d, %d steps" % (cores, B, n_steps))
+    x0, noises = O.draw_noises(1234, B, T, z, N)
+    log("C1 on the CPU oracle: %d threads, B=%d, T=%d, N=%d" % (cores, B, T, N))
+    rec = []
     with torch.no_grad():
         t0 = time.time()
-        eps = O.sample_discrete(sde, fn, x0, noises, cfg.sde.sample_N, max_steps=n_steps)
-        t1 = time.time()
-        O.compressor_decode(sd_c, cfg.compressor, eps)
-        t2 = time.time()
-    t_step = (t1 - t0) / n_steps
-    per_call = cfg.sde.sample_N * t_step + (t2 - t1)
-    return {"value": B / per_call, "unit": "shapes/sec", "cores": cores, "kind": "port",
-            "sample": "oracle (PyTorch-CPU fp32 restatement of the reference, %d threads): B=%d shapes, T=%d tokens, first %d "
-                      "of %d ancestral steps (%.3f s/step) + 1 decode (%.2f s); extrapolated linearly to %d steps"
-                      % (cores, B, cfg.score.z_scale, n_steps, cfg.sde.sample_N, t_step, t2 - t1, cfg.sde.sample_N)}
+        ref_pts, ref_eps = O.trainer_sample(sd_s, sd_c, cfg, x0, noises, record=rec)
+        t_cpu = time.time() - t0
+        g = torch.Generator().manual_seed(0)               # conditioning of the decode map at these (random-weight) latents
+        pert = O.compressor_decode(sd_c, cfg.compressor, ref_eps * (1 + 2 ** -9 * torch.randn(ref_eps.shape, generator=g)))
+    log("C1 oracle done: %.1f s" % t_cpu)
+    tr100 = ldt_amd.Trainer(cfg, trainer.model, trainer.compressor, trainer.device)
+    traj = []
+    pts, eps = tr100.sample(B, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    tr100.sample(B, x0=x0, noise=torch.stack(noises))
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    xs = traj[0].cpu()                                      # [N, B, T, z]: x after every step
+    per_step = [rel_mse(xs[i], rec[i][3]) for i in range(N)]
+    r2 = (ref_pts ** 2).sum(-1).mean(1)
+    cd = float((O.chamfer_cd(pts.cpu(), ref_pts) / r2).max())
+    floor_pts = rel_mse(pert, ref_pts)
+    floor_cd = float((O.chamfer_cd(pert, ref_pts) / r2).max())
+    parity = {"config": "C1: B=4, T=%d, N=%d ancestral, injected x0 + per-step noise (seed 1234), decode to %d points" % (T, N, ref_pts.shape[1]),
+              "per_step_max": max(per_step), "per_step_last": per_step[-1], "final_latent": rel_mse(eps.cpu(), ref_eps),
+              "points_rel_mse": rel_mse(pts.cpu(), ref_pts), "chamfer_norm": cd,
+              "decode_conditioning": {"what": "the fp32 oracle's own decode under one bf16 rounding (2^-9 relative) of its latents",
+                                      "points_rel_mse": floor_pts, "chamfer_norm": floor_cd},
+              "tol": {"per_step": 1e-4, "final_latent": 1e-4, "chamfer_norm": max(2e-3, 4 * floor_cd),
+                      "points_rel_mse": max(2e-3, 4 * floor_pts), "metric": "relative MSE |a-b|^2/|b|^2; Chamfer / mean squared radius"},
+              "gpu_seconds": round(t_gpu, 3)}
+    parity["pass"] = bool(parity["per_step_max"] <= 1e-4 and parity["final_latent"] <= 1e-4 and cd <= parity["tol"]["chamfer_norm"]
+                          and parity["points_rel_mse"] <= parity["tol"]["points_rel_mse"])
+    base = {"value": (B / t_cpu) / 10.0, "unit": "shapes/sec", "cores": cores, "kind": "port",
+            "sample": "config C1 exactly: oracle (PyTorch-CPU fp32 restatement of the reference, pinned to reference-captured goldens), "
+                      "%d threads, B=%d shapes, T=%d tokens, N=%d ancestral steps + decode = %.1f s wall; x 1/10 for N=1000 "
+                      "(per-step cost is step-invariant)" % (cores, B, T, N, t_cpu),
+            "c1_seconds": round(t_cpu, 2), "c1_shapes_per_sec_at_N100": B / t_cpu}
+    return base, parity
+
+
+# ----------------------------------------------------------------------------------------------------------- extras
+def _timed(fn, reps=2):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, r
+
+
+def extra_c4(tokens=256, batch=1024, chunk=128):
+    """BASELINE configs[3]: Compressor encode + decode only (2048 -> T tokens -> 2048), batch 1024, 1 GPU, and the
+    cross-attention kernel on its own in both orientations.  CPU baseline: the oracle on a bounded sample of clouds."""
+    import ldt_amd
+    from ldt_amd import ops
+    from oracle import ldt_oracle as O
+    cfg = ldt_amd.airplane_config(latent_tokens=tokens)
+    torch.manual_seed(0)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    comp.init()
+    sd_c = {k: v.detach().float().clone() for k, v in comp.state_dict().items()}
+    comp = comp.cuda()
+    g = torch.Generator().manual_seed(2)
+    pts_h = torch.randn(batch, 2048, 3, generator=g)
+    pts_h = pts_h - pts_h.mean(1, keepdim=True)
+    pts_h = pts_h / pts_h.norm(dim=-1).amax(1)[:, None, None]
+    pts = pts_h.cuda()
+    t_enc, eps = _timed(lambda: torch.cat([comp(pts[i:i + chunk])["all_eps"] for i in range(0, batch, chunk)]))
+    t_dec, dec = _timed(lambda: comp.sample((batch, 2048), given_eps=eps))
+    assert bool(torch.isfinite(dec).all())
+    cc = cfg.compressor
+    d, L, T = cc.hidden_dim, cc.n_layers, tokens
+    # SURVEY §8d decode FLOPs per shape: L x (q/o + MLP on 2048 rows, cross-attention 2048 x T, ln + kv on T rows) x 2
+    dec_flops = L * (2048 * (2 * d * d + 2 * d * 4 * d) + 2 * 2048 * T * d + T * (cc.z_dim * d + d * 2 * d)) * 2.0
+    dec_tf = dec_flops * batch / t_dec / 1e12
+    # unfused lower bound of the decode (SURVEY §8d "unfused: 2 MB x passes per shape and layer"): the fp32 set O
+    # (2048 x d) read + written by each of the block's 7 kernels -> HBM-bound time at 8 TB/s
+    unfused_bytes = L * 7 * 2 * 2048 * d * 4.0
+    unfused_clouds_s = PEAK_HBM_GBS * 1e9 / unfused_bytes
+    # cross-attention kernel alone (d = 128, 4 heads x 32), 128 clouds per launch
+    Bm, H, dh = 128, cc.num_heads, d // cc.num_heads
+
+    def attn_time(fn, n=20):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    q = torch.randn(Bm * 2048, d, device="cuda").to(torch.bfloat16)
+    kv = torch.randn(Bm * T, 2 * d, device="cuda").to(torch.bfloat16)
+    o = torch.empty(Bm, H, 2048, dh, device="cuda", dtype=torch.bfloat16)
+    t1 = attn_time(lambda: ops.attention_fwd(q, kv[:, :d], kv[:, d:], Bm, H, 2048, T, dh, out=o))
+    b1 = (2 * Bm * 2048 * d + 2 * Bm * T * d) * 2.0
+    q2 = torch.randn(Bm * T, d, device="cuda").to(torch.bfloat16)
+    kv2 = torch.randn(Bm * 2048, 2 * d, device="cuda").to(torch.bfloat16)
+    o2 = torch.empty(Bm, H, T, dh, device="cuda", dtype=torch.bfloat16)
+    t2 = attn_time(lambda: ops.attention_fwd(q2, kv2[:, :d], kv2[:, d:], Bm, H, T, 2048, dh, out=o2))
+    # CPU oracle on a bounded sample
+    nb = 8
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        noise = [torch.randn(nb, T, cc.z_dim) for _ in range(L)]
+        t0 = time.time(); r = O.compressor_encode(sd_c, cc, pts_h[:nb], noise); t_ce = time.time() - t0
+        t0 = time.time(); O.compressor_decode(sd_c, cc, r["all_eps"]); t_cd = time.time() - t0
+
+    def hb(bytes_, t):
+        gbs = bytes_ / t / 1e9
+        return {"us": round(t * 1e6, 1), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "bound": "hbm", "bytes_per_launch": bytes_, "clouds_per_launch": Bm}
+
+    return {"workload": "BASELINE configs[3]: Compressor encode+decode only, batch %d, 2048 pts <-> %d tokens, 1 GPU" % (batch, T),
+            "encode_clouds_per_s": round(batch / t_enc, 1), "decode_clouds_per_s": round(batch / t_dec, 1),
+            "encode_decode_clouds_per_s": round(batch / (t_enc + t_dec), 1),
+            "decode_roofline": {"bound": "mfma", "achieved": round(dec_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(dec_tf / PEAK_BF16_TFLOPS, 4), "flops_per_cloud": dec_flops},
+            "decode_unfused_lower_bound": {"what": "7 kernels per block each reading + writing the fp32 (2048 x %d) set at 8 TB/s" % d,
+                                           "clouds_per_s": round(unfused_clouds_s, 1), "bytes_per_cloud": unfused_bytes,
+                                           "measured_over_bound": round(batch / t_dec / unfused_clouds_s, 3)},
+            "cross_attn_q2048_kvT": hb(b1, t1), "cross_attn_qT_kv2048": hb((2 * Bm * T * d + 2 * Bm * 2048 * d) * 2.0, t2),
+            "cpu_baseline": {"encode_clouds_per_s": round(nb / t_ce, 3), "decode_clouds_per_s": round(nb / t_cd, 3), "cores": host_cores(),
+                             "kind": "port", "sample": "oracle compressor_encode / compressor_decode on %d of the %d clouds" % (nb, batch)}}
+
+
+def extra_sampling(score, tokens, batch, n_steps, vipc, cpu_steps=6):
+    """A sampling workload at `tokens` latent tokens: shapes/s of Trainer.sample(batch) with n_steps SDE steps (+ decode), its
+    whole-job MFMA fraction, and a bounded CPU-oracle baseline (B=4, first `cpu_steps` steps, extrapolated linearly)."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    cfg = ldt_amd.airplane_config(latent_tokens=tokens, sample_N=n_steps)
+    torch.manual_seed(1)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    comp.init()
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    cond, S = None, 32
+    if vipc:                                              # synthetic ConditionNet outputs (SURVEY §8d C5)
+        g = torch.Generator().manual_seed(5)
+        cond = (torch.randn(batch, cfg.score.hidden_size, S, generator=g).cuda(), torch.randn(batch, cfg.score.t_dim, generator=g).cuda())
+    dt, (pts, eps) = _timed(lambda: tr.sample(batch, condition=cond), reps=1)
+    assert bool(torch.isfinite(eps).all())
+    flops = score_flops_per_sample_step(cfg) * n_steps * batch
+    if vipc:                                              # + per-sample AdaLN rows (6 D t_dim per block + final) per sample-step
+        D, L = cfg.score.hidden_size, cfg.score.num_blocks
+        flops += 2.0 * (L * 6 * D + 2 * D) * cfg.score.t_dim * n_steps * batch
+    tf = flops / dt / 1e12
+    # bounded CPU sample
+    torch.set_num_threads(host_cores())
+    sd_s = {k: v.detach().float().cpu() for k, v in score.state_dict().items()}
+    Bc = 4
+    x0, noises = O.draw_noises(7, Bc, tokens, cfg.score.z_dim, cpu_steps)
+    sde = O.VPSDE(cfg.sde)
+    cnd = None if not vipc else (cond[0][:Bc].cpu().transpose(1, 2).contiguous(), cond[1][:Bc].cpu())
+    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd_s, cfg.score, x, t, condition=cnd))
+    with torch.no_grad():
+        t0 = time.time()
+        O.sample_discrete(sde, fn, x0, noises, n_steps, max_steps=cpu_steps)
+        t_step = (time.time() - t0) / cpu_steps
+    return {"shapes_per_s": round(batch / dt, 3), "ms_per_sde_step": round(1e3 * dt / n_steps, 3), "seconds_per_call": round(dt, 3),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                         "scope": "whole job (Score flops of SURVEY §8d / wall time)"},
+            "cpu_baseline": {"value": Bc / (n_steps * t_step), "unit": "shapes/sec", "cores": host_cores(), "kind": "port",
+                             "sample": "oracle, B=%d, T=%d, first %d of %d steps (%.3f s/step), extrapolated linearly, decode excluded"
+                                       % (Bc, tokens, cpu_steps, n_steps, t_step)}}
 
 
 def main():
@@ -178,14 +373,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ                      # under torch.distributed.run: the collective path runs even at world 1
+    torch.cuda.set_device(local_rank)
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", init_method="env://")       # RCCL over xGMI; MASTER_* / RANK from the launcher
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
     device = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
 
     import ldt_amd
     cfg = ldt_amd.airplane_config(latent_tokens=args.tokens, sample_N=args.sde_steps)
@@ -197,7 +392,7 @@ def main():
     B = args.batch_per_gpu * world
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
@@ -213,7 +408,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     log("timed region: %.2f s for %d sample() calls" % (dt, args.steps))
-    if world > 1:
+    if launched:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -232,20 +427,42 @@ def main():
                                    % (args.batch_per_gpu, args.tokens, cfg.score.z_dim, args.sde_steps, cfg.data.tr_max_sample_points),
                        "global_batch": B, "batch_per_gpu": args.batch_per_gpu, "latent_tokens": args.tokens,
                        "sde_steps": args.sde_steps, "points": cfg.data.tr_max_sample_points,
-                       "parallelism": "dp%d batch slices, one all-gather" % world},
+                       "parallelism": "dp%d batch slices, one all-gather" % world,
+                       "collective": ("%s, world %d" % (dist.get_backend(), world)) if launched else "none (single process)"},
             "achieved_tflops_whole_job": round(flops_call * args.steps / dt / 1e12, 1),
+            "whole_job_mfma_frac": round(flops_call * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
         if not args.no_roofline:
-            roof, attn, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
+            roof, roofs, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
             log("roofline pass done: %s" % json.dumps(kernels))
             line["roofline"] = roof
-            line["roofline_attention"] = attn
+            line["roofline_attention"] = roofs.get("attention")
+            line["roofline_kernels"] = roofs
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(trainer, cfg, args.cpu_steps)
-            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+            base, parity = c1_baseline_and_parity(trainer, cfg)
+            line["cpu_baseline"] = base
+            line["parity"] = parity
+            line["speedup_vs_cpu"] = round(value / base["value"], 1)
+            log("parity: %s" % json.dumps({k: parity[k] for k in ("per_step_max", "final_latent", "chamfer_norm", "pass")}))
+        if world == 1 and not args.no_extras:
+            extra = {}
+            for name, fn in (("c4_compressor_b1024", lambda: extra_c4()),
+                             ("c5_vipc_share_b32_t32", lambda: dict(workload="BASELINE configs[4] per-GPU share: ViPC-conditioned sampling, 32 shapes/GPU, "
+                                                                    "32 latent tokens, 32 condition tokens, 1000 steps", **extra_sampling(score, 32, 32, 1000, True))),
+                             ("shipped_t32_b64", lambda: dict(workload="shipped airplane YAML (32 latent tokens), batch 64, 1000 steps",
+                                                              **extra_sampling(score, 32, 64, 1000, False)))):
+                if time.time() - _T0 > args.budget_s:
+                    extra[name] = {"skipped": "run older than --budget-s %.0f s" % args.budget_s}
+                    continue
+                try:
+                    extra[name] = fn()
+                    log("extra %s: %s" % (name, json.dumps(extra[name])[:400]))
+                except Exception as e:                    # noqa: BLE001 — an extra block must not cost the headline line
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            line["extra"] = extra
         print(json.dumps(line))
-    if world > 1:
+    if launched:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

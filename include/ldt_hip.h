@@ -264,9 +264,10 @@ enum ldt_prof_class {
     LDT_PROF_LN = 2,          /* LayerNorm + AdaLN modulate               */
     LDT_PROF_GEMM_QKV = 3,    /* fc_q|fc_kv                (gemm<BF16>)  */
     LDT_PROF_ATTN = 4,        /* fused attention                          */
-    LDT_PROF_GEMM_RESID = 5,  /* fc_o, mlp.out + gate+res  (gemm<RESID>) */
+    LDT_PROF_GEMM_O = 5,      /* fc_o + gate + residual    (gemm<RESID>, K = hidden)     */
     LDT_PROF_GEMM_GELU = 6,   /* mlp.fc + GELU             (gemm<GELU>)  */
-    LDT_PROF_NCLASS = 7
+    LDT_PROF_GEMM_DN = 7,     /* mlp.out + gate + residual (gemm<RESID>, K = mlp_hidden) */
+    LDT_PROF_NCLASS = 8
 };
 int ldt_score_forward_profile(const ldt_score_plan* plan, const float* x, float* eps_out, const int32_t* step_ptr,
                               float* ms_by_class, int32_t* launches_by_class, void* stream);
@@ -287,12 +288,13 @@ typedef struct ldt_cond_args {
 /* The whole reverse-SDE loop (pc_sampling, diffusion_continuous.py:231-258 with corrector None): n_steps x
  * [(AdaLN rows if cond) -> Score forward -> predictor update -> ++step].  x is updated in place, x_mean receives the
  * last x_mean (denoise=True returns it, quirk Q8).  step_counter: device int32 scratch.  cond: NULL for the
- * unconditional sampler (plan->mod = table of all steps).  use_graph != 0 captures one step into a hipGraph and
- * replays it. */
+ * unconditional sampler (plan->mod = table of all steps).  x_traj: NULL, or [n_steps][batch*tokens*z_dim] fp32 that
+ * receives x after every step (the per-step parity curve against the CPU reference).  use_graph != 0 captures one step
+ * into a hipGraph and replays it. */
 int ldt_sample_loop(const ldt_score_plan* plan, float* x, float* x_mean, float* eps_tmp,
                     const float* coef, int32_t mode, const float* noise, int64_t noise_step_stride,
                     int64_t elem_offset, uint64_t seed, int32_t* step_counter, int32_t n_steps,
-                    const ldt_cond_args* cond, int32_t use_graph, void* stream);
+                    const ldt_cond_args* cond, float* x_traj, int32_t use_graph, void* stream);
 
 /* ---- measurement knob (tools/dbg/gm_bench.py): rows per group of the persistent GEMM's grouped tile order
  * (1 = row-major, the default; LDT_GEMM_GM sets it at start-up).  Process-wide; not used by the product path. */

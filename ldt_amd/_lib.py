@@ -13,7 +13,7 @@ MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = range(4)
-PROF_CLASSES = ("other", "gemm_io", "ln_modulate", "gemm_qkv", "attention", "gemm_resid", "gemm_gelu")
+PROF_CLASSES = ("other", "gemm_io", "ln_modulate", "gemm_qkv", "attention", "gemm_o", "gemm_gelu", "gemm_dn")
 
 _vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -76,7 +76,7 @@ SIGNATURES = {
     "ldt_score_forward": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp],
     "ldt_score_forward_profile": [C.POINTER(ScorePlan), _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp],
     "ldt_dbg_gemm_group_m": [_i32],
-    "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, C.POINTER(CondArgs), _i32, _vp],
+    "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, C.POINTER(CondArgs), _vp, _i32, _vp],
 }
 
 _lib = None

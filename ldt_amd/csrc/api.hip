@@ -283,25 +283,25 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             // fc_o + gate + residual, also emitting Hb = x (1 + scale_mlp) and the row statistics; mlp.fc consumes them
             GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D,
                         BFM(p->Hb), D, m + 4 * D, tstr, p->stats};
-            go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
+            go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
             GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, nullptr, p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, F, D,
                         nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl + 6L * D, fl + 6L * D + F, fstep};
             gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
             GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F,
                         BFM(p->Hb), D, m + 6 * D + D, tstr, p->stats};      // next block's scale_msa
             gd.max_wgs = p->gemm_wgs;
-            if (l + 1 < p->blocks) LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
-            else LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
+            if (l + 1 < p->blocks) LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
+            else LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
             continue;
         }
         GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
-        go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
+        go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
         LnArgs n2{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m + 3 * D, m + 4 * D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n2, s));
         GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, p->b_up[l], p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, F, D};
         gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_launch(LDT_EPI_GELU_BF16, &gu, s));
         GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F};
-        gd.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_RESID, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
+        gd.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
     }
     {                                                           // FinalLayer (layers.py:240-248)
         const float* m = p->mod + (long)p->blocks * 6 * D;
@@ -339,7 +339,7 @@ extern "C" int ldt_score_forward_profile(const ldt_score_plan* p, const float* x
 // ------------------------------------------------------------------------------ reverse-SDE loop
 static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef, int mode,
                         const float* noise, long noise_step_stride, long elem_offset, uint64_t seed, int* step_counter,
-                        const ldt_cond_args* cond, hipStream_t s) {
+                        const ldt_cond_args* cond, float* x_traj, hipStream_t s) {
     if (cond) {                                                 // per-sample AdaLN rows of this step
         TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, step_counter, p->batch, cond->t_dim, s));
         SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_SILU,
@@ -349,7 +349,7 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
     TRY(score_forward_impl(p, x, eps_tmp, cond ? nullptr : step_counter, s, nullptr));
     const long n = (long)p->batch * p->tokens * p->z_dim;
     StepArgs st{x, eps_tmp, noise, x, x_mean, coef, step_counter, 0, mode, n, elem_offset, noise_step_stride,
-                (uint32_t)seed, (uint32_t)(seed >> 32), 1, 0};
+                (uint32_t)seed, (uint32_t)(seed >> 32), 1, 0, x_traj};
     TRY(ldt_sampler_step_launch(&st, s));
     return ldt_advance_step_launch(step_counter, s);
 }
@@ -357,7 +357,7 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
 extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean, float* eps_tmp, const float* coef,
                                int32_t mode, const float* noise, int64_t noise_step_stride, int64_t elem_offset,
                                uint64_t seed, int32_t* step_counter, int32_t n_steps, const ldt_cond_args* cond,
-                               int32_t use_graph, void* stream) {
+                               float* x_traj, int32_t use_graph, void* stream) {
     TRY(check_plan(p));
     LDT_REQUIRE(x && x_mean && eps_tmp && coef && step_counter && n_steps > 0, LDT_EARG, "sample_loop: null pointer / n_steps");
     LDT_REQUIRE(!cond || (cond->temb && cond->w_ada && cond->c_buf && cond->mod_buf && cond->mod_buf == p->mod &&
@@ -368,7 +368,7 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     if (e != hipSuccess) { ldt_set_error("sample_loop: memset: %s", hipGetErrorString(e)); return (int)e; }
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i)
-            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, s));
+            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, s));
         return LDT_OK;
     }
     // One step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter.
@@ -397,7 +397,7 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     if (status == LDT_OK) {
         HIPTRY(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal), "begin capture");
         if (status == LDT_OK) {
-            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, gs);
+            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, gs);
             const hipError_t ee = hipStreamEndCapture(gs, &graph);
             if (rc != LDT_OK) status = rc;
             else if (ee != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(ee)); status = (int)ee; }

@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
             }
         }
         *reinterpret_cast<f32x4*>(a.x_out + 4 * i) = xn;
+        if (a.traj) *reinterpret_cast<f32x4*>(a.traj + (long)step * a.n + 4 * i) = xn;
         if (a.x_mean_out) *reinterpret_cast<f32x4*>(a.x_mean_out + 4 * i) = xm;
     }
 }

@@ -59,6 +59,7 @@ struct StepArgs {
     long n; long elem_offset; long noise_step_stride;
     uint32_t seed_lo, seed_hi;
     int philox_mul, philox_add;          // Philox stream id of this draw = step * philox_mul + philox_add
+    float* traj;                         // optional [n_steps][n]: x after this step is also stored at traj + step*n (parity curves)
 };
 
 struct SgemmArgs {

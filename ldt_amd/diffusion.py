@@ -149,7 +149,8 @@ class DiffusionVPSDE:
     @torch.no_grad()
     def sample_discrete(self, score_fn, num_samples, N, predictor, corrector, corrector_steps, shape, time_eps,
                         probability_flow, denoise, snr, device, condition=None, label=None, print_steps=None,
-                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None, streams=None, global_batch=None):
+                        *, x0=None, noise=None, sample_offset=0, seed=None, use_graph=None, record=None, streams=None, global_batch=None,
+                        trajectory=None):
         """Reverse-SDE predictor(-corrector) sampling, diffusion_continuous.py:133-338.
 
         corrector: None, 'ancestral' (AncestralCorrector :212-229; alpha = 1 by the reference's quirk Q11) or 'langevin'
@@ -159,7 +160,8 @@ class DiffusionVPSDE:
         error otherwise; the same rule is applied here to the GLOBAL batch (`global_batch`, default num_samples).
         Langevin's step size uses batch means of norms — under a sharded batch the two norm sums are all-reduced (the one
         cross-sample quantity on the path); everything else stays per rank.
-        print_steps: the trajectory dump of :239-257 (returns the list of tensors)."""
+        print_steps: the trajectory dump of :239-257 (returns the list of tensors).
+        trajectory: a list; the fused loop appends ONE tensor [N, B, tokens, z] holding x after every step (parity curves)."""
         if corrector not in (None, "ancestral", "langevin"):
             raise NotImplementedError("corrector not Implemented")           # diffusion_continuous.py:335
         gb = num_samples if global_batch is None else int(global_batch)
@@ -215,6 +217,7 @@ class DiffusionVPSDE:
                 Bs = hi - lo
                 xs, xm = x[lo:hi], x_mean[lo:hi]                                      # contiguous row slices, updated in place
                 eps_tmp = torch.empty_like(xs)
+                tj = None if trajectory is None else torch.empty((N,) + tuple(xs.shape), dtype=torch.float32, device=dev)
                 counter = torch.zeros(1, dtype=torch.int32, device=dev)
                 nz = None if noise is None else noise[:, lo:hi]
                 wgs = 0 if streams == 1 else max(256 // streams, 1)
@@ -235,14 +238,14 @@ class DiffusionVPSDE:
                     keep.append((ex, kvs, c_buf, modb, cond))
                 if nz is not None and streams > 1:
                     nz = nz.contiguous()                                              # [N, Bs, T, z] with step stride Bs*T*z
-                jobs.append((plan, xs, xm, eps_tmp, counter, nz, cond_ref, elem_offset + lo * int(np.prod(shape))))
+                jobs.append((plan, xs, xm, eps_tmp, counter, nz, cond_ref, elem_offset + lo * int(np.prod(shape)), tj))
 
             def run(job, stream):
-                plan, xs, xm, eps_tmp, counter, nz, cond_ref, off = job
+                plan, xs, xm, eps_tmp, counter, nz, cond_ref, off, tj = job
                 with torch.cuda.stream(stream):
                     check(lib().ldt_sample_loop(ctypes.byref(plan), xs.data_ptr(), xm.data_ptr(), eps_tmp.data_ptr(),
                                                 coef_d.data_ptr(), mode, ops._p(nz), xs.numel() if nz is not None else 0, off, seed,
-                                                counter.data_ptr(), N, cond_ref, int(bool(use_graph)), ops.stream_ptr()),
+                                                counter.data_ptr(), N, cond_ref, ops._p(tj), int(bool(use_graph)), ops.stream_ptr()),
                           "ldt_sample_loop")
 
             main = torch.cuda.current_stream()
@@ -272,6 +275,8 @@ class DiffusionVPSDE:
                     main.wait_stream(st)
             if keep or streams > 1:
                 main.synchronize()                                                    # scratch / sub-streams must outlive the loop
+            if trajectory is not None:
+                trajectory.append(torch.cat([j[-1] for j in jobs], 1))
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)
@@ -287,6 +292,7 @@ class DiffusionVPSDE:
             per = int(np.prod(shape))
             n_valid = max(0, min(num_samples, gb - int(sample_offset)))
         out_list, every = None, None
+        traj_list = [] if trajectory is not None else None
         if print_steps is not None:
             out_list, every = [x.clone()], (N - 1) // (print_steps - 2)
         for i in range(N):
@@ -323,8 +329,12 @@ class DiffusionVPSDE:
                 check(lib().ldt_langevin_coef(lv_sums.data_ptr(), gb, float(snr), float(std_host[i]), lv_coef.data_ptr(), st),
                       "ldt_langevin_coef")
                 x = ops.sampler_step(x, params, lv_coef, 0, 1, noise=z, x_mean_out=x_mean)
+            if traj_list is not None:
+                traj_list.append(x.clone())
             if out_list is not None and (i + 1) % every == 0:
                 out_list.append(x_mean.clone())
+        if traj_list is not None:
+            trajectory.append(torch.stack(traj_list))
         if out_list is not None:
             out_list.append((x_mean if denoise else x).clone())
             return out_list

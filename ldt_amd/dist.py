@@ -6,8 +6,12 @@ import torch
 import torch.distributed as dist
 
 
+def initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
 def world():
-    if dist.is_available() and dist.is_initialized():
+    if initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
@@ -23,9 +27,9 @@ def shard_bounds(num_samples, rank, world_size):
 def all_gather_rows(local, num_samples):
     """local [per, ...] on every rank -> [num_samples, ...] (same on every rank): the single collective."""
     rank, ws = world()
-    if ws == 1:
+    if not initialized():
         return local[:num_samples]
-    local = local.contiguous()
+    local = local.contiguous()                  # (a launched world of 1 still goes through the collective: same code path as N > 1)
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
     return out[:num_samples]
@@ -37,12 +41,13 @@ def check_same_draws(x0, seed, device):
     tools/utils.py:269-276).  One 16-byte all-gather of (key, bit pattern of sum(x0)) — control plane, not the data path —
     turns a silent mismatch into an error."""
     rank, ws = world()
-    if ws == 1:
+    if not initialized():
         return
     dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.tensor([0 if seed is None else int(seed), int(x0.double().sum().view(torch.int64).item())], dtype=torch.int64, device=dev)
-    allv = torch.empty((ws, 2), dtype=torch.int64, device=dev)
+    allv = torch.empty((ws * 2,), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allv, mine)
+    allv = allv.view(ws, 2)
     if not bool((allv == allv[0]).all()):
         raise RuntimeError("Trainer.sample: ranks drew different x0 / noise keys (rank %d: %s; rank 0: %s) — seed the CPU generator "
                            "identically on every rank (torch.manual_seed) or pass x0= / seed=" % (rank, mine.tolist(), allv[0].tolist()))

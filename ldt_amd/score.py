@@ -323,6 +323,27 @@ class Score(nn.Module):
               "ldt_score_forward")
         return out
 
+    @torch.no_grad()
+    def forward_shared_t(self, x, t, fold=None):
+        """One Score evaluation with every sample at the SAME time `t` (a float) — what each step of the fused sampling
+        loop runs (diffusion_continuous.py:243-244 builds vec_t = ones * t): batch-shared AdaLN rows and, where
+        `can_fold(B, T)` holds (or fold=True forces it), the LN-folded GEMM epilogues.  Same plan and kernels as
+        `ldt_sample_loop`'s step; used by the full-size parity tests and bench.py's per-kernel timing."""
+        if not x.is_cuda:
+            raise RuntimeError("Score.forward_shared_t: x is on %s; the HIP path has no CPU fallback" % x.device)
+        if self.unet:
+            raise NotImplementedError("forward_shared_t: the U-Net variant is host-driven (forward)")
+        B, T, z = x.shape
+        assert z == self.z_dim
+        x = x.contiguous().float()
+        _, mod = self.time_table(torch.tensor([float(t)], dtype=torch.float32, device=x.device))
+        use_fold = self.can_fold(B, T) if fold is None else bool(fold)
+        plan = self.plan(B, T, mod, self.n_mod, 0, fold=self.fold_table(mod) if use_fold else None)
+        out = torch.empty_like(x)
+        check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), None, ops.stream_ptr()),
+              "ldt_score_forward")
+        return out
+
     def _forward_unet(self, x, t, label, condition):
         """`unet: True` variant (score.py:138-146): num_blocks//2 up blocks whose outputs are kept, a mid block, then
         num_blocks//2 down blocks on cat(x, skip) (width 2*hidden -> hidden, conv shortcut, adaLN1/adaLN2).  Host-driven:

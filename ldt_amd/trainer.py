@@ -76,7 +76,7 @@ class Trainer:
 
     @torch.no_grad()
     def sample(self, num_samples, num_points=None, label=None, condition=None, *, x0=None, noise=None, seed=None,
-               use_graph=None):
+               use_graph=None, trajectory=None):
         self.model.eval()
         self.compressor.eval()
         self.optimizer.swap_parameters_with_ema(store_params_in_ema=True)
@@ -92,7 +92,7 @@ class Trainer:
                 x0 = torch.randn((num_samples,) + shape)
             if seed is None and noise is None and self.sample_mode == "discrete":
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # Philox key (only when device noise will be drawn)
-            if ws > 1:
+            if ldist.initialized():
                 ldist.check_same_draws(x0, seed, self.device)            # world-size invariance needs identical CPU generators
             x0_loc = _rows(x0, lo, hi, per)
             noise_loc = None if noise is None else _rows(noise.transpose(0, 1), lo, hi, per).transpose(0, 1)
@@ -115,10 +115,11 @@ class Trainer:
                                                device=self.device, num_samples=per,
                                                probability_flow=self.cfg.sde.probability_flow, snr=self.cfg.sde.snr,
                                                condition=condition, x0=x0_loc, noise=noise_loc, sample_offset=lo,
-                                               seed=seed, use_graph=use_graph, global_batch=num_samples if ws > 1 else None)
+                                               seed=seed, use_graph=use_graph, global_batch=num_samples if ws > 1 else None,
+                                               trajectory=trajectory)
             npts = self.num_points if num_points is None else num_points
             sample = self.compressor.sample((per, npts), given_eps=eps)
-            if ws > 1:                                   # the single collective of the path
+            if ldist.initialized():                      # the single collective of the path
                 sample = ldist.all_gather_rows(sample, num_samples)
                 eps = ldist.all_gather_rows(eps, num_samples)
         finally:

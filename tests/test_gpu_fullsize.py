@@ -1,0 +1,95 @@
+"""GPU (-m gpu): parity at the PRODUCTION size — the shipped Score (hidden 1024, 16 heads, 24 blocks, 457 M parameters) at
+256 latent tokens, seeded weights, against the CPU oracle:
+
+  * B = 64 teacher-forced forward (M = 16,384 rows): the path bench.py times — persistent 256^2 GEMMs with the LayerNorm
+    folded into their epilogues (`gemm_bf16_nt_256_kernel<1,2> / <2,2> / <4,1>`), streaming attention — and the
+    LayerNorm-kernel path on the same input;
+  * BASELINE config C1 exactly: B = 4, N = 100 ancestral steps with injected noise, through Trainer.sample: per-step
+    relative-MSE curve of the latents, final latents, decoded cloud and its Chamfer distance (normalised by the cloud's mean
+    squared radius), with the decode bar calibrated by the oracle's own sensitivity (random weights: tests/test_gpu_path.py).
+
+Tolerances (relative MSE |a-b|^2/|b|^2): forward <= 1e-4; every step and the final latents <= 1e-4 (north-star:
+"per-step MSE and final Chamfer within a stated fp tolerance").  The oracle passes take ~20 s + ~60 s of CPU."""
+import copy
+
+import pytest
+import torch
+
+from conftest import rel_mse
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    cfg = ldt_amd.airplane_config(latent_tokens=256, sample_N=100)
+    assert (cfg.score.hidden_size, cfg.score.num_heads, cfg.score.num_blocks) == (1024, 16, 24)
+    torch.manual_seed(0)
+    score = ldt_amd.Score(cfg.score)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    comp.init()
+    sd_s = {k: v.detach().clone() for k, v in score.state_dict().items()}
+    sd_c = {k: v.detach().clone() for k, v in comp.state_dict().items()}
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    return dict(cfg=cfg, tr=tr, score=tr.model, comp=tr.compressor, sd_s=sd_s, sd_c=sd_c, O=O)
+
+
+def test_fullsize_teacher_forced_b64(full):
+    O, cfg, score = full["O"], full["cfg"], full["score"]
+    B, T, z = 64, 256, cfg.score.z_dim
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, T, z, generator=g)
+    t = 0.37
+    assert score.can_fold(B, T)                                   # the production decision for this batch
+    folded = score.forward_shared_t(x.cuda(), t)
+    unfolded = score.forward_shared_t(x.cuda(), t, fold=False)    # LayerNorm kernels instead of the folded epilogues
+    per_sample = score(x.cuda(), torch.full((B,), t).cuda())      # per-sample AdaLN rows (the generic / conditioned path)
+    with torch.no_grad():
+        ref = O.score_forward(full["sd_s"], cfg.score, x, torch.full((B,), t))
+    e_f, e_u, e_p = rel_mse(folded.cpu(), ref), rel_mse(unfolded.cpu(), ref), rel_mse(per_sample.cpu(), ref)
+    print("full-size B=64 forward rel-MSE vs oracle: folded %.3e, LayerNorm kernels %.3e, per-sample rows %.3e" % (e_f, e_u, e_p))
+    assert e_f < 1e-4 and e_u < 1e-4 and e_p < 1e-4
+    assert e_f < 4 * max(e_u, 1e-7)                               # folding does not cost accuracy at K = 1024 / 4096, 24 blocks
+    # a second time: t at the end of the schedule (AdaLN rows of t = 1e-6), inflated input scale
+    x2 = x * 30.0
+    with torch.no_grad():
+        ref2 = O.score_forward(full["sd_s"], cfg.score, x2[:8], torch.full((8,), 1e-6))
+    out2 = score.forward_shared_t(x2.cuda(), 1e-6)
+    assert rel_mse(out2[:8].cpu(), ref2) < 1e-4
+
+
+def test_c1_exact_free_running(full):
+    """BASELINE configs[0] / SURVEY §8d C1: B=4, T=256, N=100, ancestral, decode included."""
+    O, cfg, tr = full["O"], full["cfg"], full["tr"]
+    B, N, T, z = 4, 100, 256, cfg.score.z_dim
+    x0, noises = O.draw_noises(1234, B, T, z, N)
+    rec = []
+    with torch.no_grad():
+        ref_pts, ref_eps = O.trainer_sample(full["sd_s"], full["sd_c"], cfg, x0, noises, record=rec)
+        g = torch.Generator().manual_seed(0)
+        pert = O.compressor_decode(full["sd_c"], cfg.compressor, ref_eps * (1 + 2 ** -9 * torch.randn(ref_eps.shape, generator=g)))
+    traj = []
+    pts, eps = tr.sample(B, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    xs = traj[0].cpu()
+    assert xs.shape == (N, B, T, z)
+    curve = [rel_mse(xs[i], rec[i][3]) for i in range(N)]
+    r2 = (ref_pts ** 2).sum(-1).mean(1)
+    cd = float((O.chamfer_cd(pts.cpu(), ref_pts) / r2).max())
+    floor_pts, floor_cd = rel_mse(pert, ref_pts), float((O.chamfer_cd(pert, ref_pts) / r2).max())
+    print("C1: per-step max %.3e (last %.3e), final latents %.3e, points %.3e (floor %.3e), Chamfer/r^2 %.3e (floor %.3e)"
+          % (max(curve), curve[-1], rel_mse(eps.cpu(), ref_eps), rel_mse(pts.cpu(), ref_pts), floor_pts, cd, floor_cd))
+    assert max(curve) < 1e-4, curve
+    assert rel_mse(eps.cpu(), ref_eps) < 1e-4
+    assert rel_mse(pts.cpu(), ref_pts) < max(2e-3, 4 * floor_pts)
+    assert cd < max(2e-3, 4 * floor_cd)
+    # the decoder alone on the ORACLE's latents (isolates Compressor.sample at the full 2048-point size)
+    dec = tr.compressor.sample((B, cfg.data.tr_max_sample_points), given_eps=ref_eps.cuda())
+    assert rel_mse(dec.cpu(), ref_pts) < max(2e-3, 4 * floor_pts)
+    g2 = torch.Generator().manual_seed(3)
+    zl = torch.randn(B, T, z, generator=g2)                        # N(0,1)-scale latents: the decoder's operating range
+    with torch.no_grad():
+        ref_dec = O.compressor_decode(full["sd_c"], cfg.compressor, zl)
+    assert rel_mse(tr.compressor.sample((B, cfg.data.tr_max_sample_points), given_eps=zl.cuda()).cpu(), ref_dec) < 1e-4
