@@ -204,7 +204,8 @@ def c1_baseline_and_parity(trainer, cfg_full):
     rec = []
     with torch.no_grad():
         t0 = time.time()
-        ref_pts, ref_eps = O.trainer_sample(sd_s, sd_c, cfg, x0, noises, record=rec)
+        ref_pts, ref_eps = O.trainer_sample(sd_s, sd_c, cfg, x0, noises, record=rec,
+                                            progress=lambda i: log("  oracle C1 step %d/%d" % (i + 1, N)) if (i + 1) % 20 == 0 else None)
         t_cpu = time.time() - t0
         g = torch.Generator().manual_seed(0)               # conditioning of the decode map at these (random-weight) latents
         pert = O.compressor_decode(sd_c, cfg.compressor, ref_eps * (1 + 2 ** -9 * torch.randn(ref_eps.shape, generator=g)))

@@ -215,7 +215,7 @@ def score_fn_from_model(sde, model_fn):
 
 def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_eps=1e-6,
                     denoise=True, probability_flow=False, record=None, max_steps=None,
-                    corrector=None, corrector_steps=1, snr=0.01, print_steps=None):
+                    corrector=None, corrector_steps=1, snr=0.01, print_steps=None, progress=None):
     """diffusion/diffusion_continuous.py:133-258,318-338 (pc_sampling).
 
     x0 [B,T,z] is the initial N(0,1) draw (:237); `noises` are the randn_like draws in consumption order: one per
@@ -226,7 +226,8 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
     PNDM (:260-316) is `sample_pndm` below.
     record: optional list that receives (x_in, params, x_mean, x_out) per predictor step.
     max_steps: stop after that many steps (bench.py's bounded CPU-baseline sample).
-    print_steps: trajectory dump of :239-257 (returns the list)."""
+    print_steps: trajectory dump of :239-257 (returns the list).
+    progress: optional callable(step index) invoked after every step (long CPU runs report that they are alive)."""
     T = 1.0
     B = x0.shape[0]
     x = x0
@@ -298,6 +299,8 @@ def sample_discrete(sde, score_fn, x0, noises, N, predictor="ancestral", time_ep
             raise NotImplementedError("corrector not Implemented")  # :335
         if print_steps is not None and (i + 1) % every == 0:
             out_list.append(x_mean)
+        if progress is not None:
+            progress(i)
     if print_steps is not None:
         out_list.append(x_mean if denoise else x)
         return out_list
@@ -574,14 +577,14 @@ def chamfer_cd(a, b):
     return dl.mean(dim=1) + dr.mean(dim=1)
 
 
-def trainer_sample(score_sd, comp_sd, cfg, x0, noises, record=None):
+def trainer_sample(score_sd, comp_sd, cfg, x0, noises, record=None, progress=None):
     """trainer/Latent_SDE_Trainer.py:143-165 Trainer.sample (discrete mode, unconditional):
     returns (points [B,N,3], eps [B,T,z])."""
     sde = VPSDE(cfg.sde)
     fn = score_fn_from_model(sde, lambda x, t: score_forward(score_sd, cfg.score, x, t))
     eps = sample_discrete(sde, fn, x0, noises, cfg.sde.sample_N, predictor=cfg.sde.predictor,
                           time_eps=cfg.sde.sample_time_eps, denoise=cfg.sde.denoise,
-                          probability_flow=cfg.sde.probability_flow, record=record)
+                          probability_flow=cfg.sde.probability_flow, record=record, progress=progress)
     pts = compressor_decode(comp_sd, cfg.compressor, eps)
     return pts, eps
 

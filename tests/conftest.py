@@ -44,3 +44,25 @@ def tiny_cfg():
 def rel_mse(a, b):
     a = a.double(); b = b.double()
     return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-300))
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota) — the GPU boxes expose every host core in
+    the affinity mask but cap the container at a quota; oversubscribed torch threads run the CPU oracle 10x slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + p // 2) // p))
+        except (OSError, ValueError):
+            pass
+    return n

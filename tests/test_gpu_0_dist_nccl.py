@@ -27,7 +27,7 @@ def _free_port():
 def test_bench_under_torchrun_world1_runs_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sde-steps", "4", "--steps", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sde-steps", "25", "--steps", "1",
            "--warmup", "0", "--batch-per-gpu", "8", "--tokens", "32", "--no-cpu-baseline", "--no-extras", "--no-roofline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

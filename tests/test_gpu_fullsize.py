@@ -15,7 +15,7 @@ import copy
 import pytest
 import torch
 
-from conftest import rel_mse
+from conftest import host_cores, rel_mse
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def full():
     import ldt_amd
     from oracle import ldt_oracle as O
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    torch.set_num_threads(host_cores())
     cfg = ldt_amd.airplane_config(latent_tokens=256, sample_N=100)
     assert (cfg.score.hidden_size, cfg.score.num_heads, cfg.score.num_blocks) == (1024, 16, 24)
     torch.manual_seed(0)
@@ -68,7 +68,11 @@ def test_c1_exact_free_running(full):
     x0, noises = O.draw_noises(1234, B, T, z, N)
     rec = []
     with torch.no_grad():
-        ref_pts, ref_eps = O.trainer_sample(full["sd_s"], full["sd_c"], cfg, x0, noises, record=rec)
+        import time
+        t0 = time.time()
+        ref_pts, ref_eps = O.trainer_sample(full["sd_s"], full["sd_c"], cfg, x0, noises, record=rec,
+                                            progress=lambda i: print("  oracle C1 step %d/%d  %.0f s" % (i + 1, N, time.time() - t0), flush=True)
+                                            if (i + 1) % 10 == 0 else None)
         g = torch.Generator().manual_seed(0)
         pert = O.compressor_decode(full["sd_c"], cfg.compressor, ref_eps * (1 + 2 ** -9 * torch.randn(ref_eps.shape, generator=g)))
     traj = []

@@ -8,6 +8,9 @@ import collections, csv, glob, json, os, re, sys
 
 tag, fdir, wdir, note = sys.argv[1:5]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_sha  # noqa: E402  (sha of ldt_amd/csrc at collection time: bench.py withholds a stale measurement)
+SHA = csrc_sha()
 
 
 def load(d, counter):
@@ -29,7 +32,8 @@ for counter, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
 for k in sorted(set(fetch) & set(write)):
     f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
     traffic[k] = {"fetch_size_kib_raw": round(f, 1), "write_size_kib": round(w, 1),
-                  "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": note}
+                  "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": note,
+                  "source": "profiles/%s_pmc_hbm_traffic.csv" % tag, "csrc_sha": SHA}
 with open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm_traffic.csv"), "w") as fo:
     fo.write("counter,kernel,launches,avg_KiB,min_KiB,max_KiB\n")
     for r in rows:
