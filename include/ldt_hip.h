@@ -299,6 +299,9 @@ int ldt_sample_loop(const ldt_score_plan* plan, float* x, float* x_mean, float* 
 /* ---- measurement knob (tools/dbg/gm_bench.py): rows per group of the persistent GEMM's grouped tile order
  * (1 = row-major, the default; LDT_GEMM_GM sets it at start-up).  Process-wide; not used by the product path. */
 int ldt_dbg_gemm_group_m(int32_t rows_per_group);
+/* tools/dbg/epi_ablate.py: skip parts of the residual epilogue (bit 1 residual read, 2 fp32 store, 4 bf16 x(1+scale) store,
+ * 8 row statistics) to attribute its time; -1 restores the product behaviour.  Process-wide; not used by the product path. */
+int ldt_dbg_gemm_epi(int32_t bits);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,8 @@
 // modulate, the fused reverse-SDE update with in-kernel Philox noise, sinusoidal time embedding,
 // and a plain fp32 tiled SGEMM for the tiny / precision-critical linears (time MLP, AdaLN tables,
 // K<=64 convs).  All are coalesced 16-B-per-lane where the shape allows (guide G13).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -333,6 +335,9 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const SgemmArgs a) {
 int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s) {
     LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, LDT_ESHAPE, "sgemm: empty problem");
     LDT_REQUIRE(a->A && a->B && a->C, LDT_EARG, "sgemm: null pointer");
+    static const bool no_mfma = getenv("LDT_SGEMM_VALU") != nullptr;      // tools/dbg A/B: force the scalar-FMA kernel
+    int st = LDT_OK;
+    if (!no_mfma && ldt_sgemm_mfma_try(a, s, &st)) return st;            // fp32-input MFMA kernel (sgemm_mfma.hip) when rows are 16-B aligned, K % 16 == 0
     dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
     LDT_REQUIRE(grid.y < 65536, LDT_ESHAPE, "sgemm: M too large for this kernel (M=%d)", a->M);
     hipLaunchKernelGGL(sgemm_nt_kernel, grid, block, 0, s, *a);

@@ -27,6 +27,7 @@ struct GemmArgs {
     // with (mean, rstd) of each row from stats_in[stats_parts][M][2] over the K input channels
     const float* stats_in; int stats_parts; const float* fold_S; const float* fold_C; long fold_step_stride;
     int group_m;                        // 256-tile kernel: row panels per group of the tile order (set by the launcher)
+    int dbg;                            // tools/dbg only (LDT_DBG_EPI bits: 1 no residual read, 2 no fp32 store, 4 no xs store, 8 no statistics)
     int max_wgs;                        // 256-tile kernel: cap on the persistent grid (0 = one workgroup per CU); sub-batch streams use 128
 };
 
@@ -79,6 +80,7 @@ int ldt_advance_step_launch(int* step_ptr, hipStream_t s);
 int ldt_philox_normal_launch(float* out, long n, long elem_offset, int step, uint32_t k0, uint32_t k1, hipStream_t s);
 int ldt_sinusoid_launch(const float* t, const float* freq, float* e, int n, int half, hipStream_t s);
 int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s);
+bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status);   // sgemm_mfma.hip: false = shape not taken
 
 int ldt_fps_launch(const float* xyz, int B, int n, int m, int* idx, hipStream_t s);
 int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, int k, int* out, float* dist_out, hipStream_t s);
