@@ -170,7 +170,7 @@ int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float*
  * ldt_reparam: mu|logvar split, clamp(logvar, lo, hi), eps = mu + exp(logvar/2)*noise into a strided slice
  *   (Network.py:26-29,75-77); mu_out/logvar_out nullable.
  * ldt_chamfer: distChamfer (evaluation/evaluation_metrics.py:23-33): dl[b][nb] = min over a, dr[b][na] = min over b. */
-int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream);
+int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t skip_near_origin, int32_t* idx_out, void* stream);
 int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_t S, int32_t k,
             int32_t* idx_out, float* dist_out, void* stream);
 int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,

@@ -61,7 +61,7 @@ SIGNATURES = {
     "ldt_langevin_coef": [_vp, _i32, C.c_float, C.c_float, _vp, _vp],
     "ldt_pndm_transfer": [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _i64, _vp],
     "ldt_lincomb4": [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _i64, _vp],
-    "ldt_fps": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "ldt_fps": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_knn": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "ldt_group_normalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "ldt_gather_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -133,9 +133,9 @@ extern "C" int ldt_philox_normal(float* out, int64_t n, int64_t elem_offset, int
 }
 
 // ------------------------------------------------------------------------------ Compressor encoder front end
-extern "C" int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t* idx_out, void* stream) {
+extern "C" int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t skip_near_origin, int32_t* idx_out, void* stream) {
     LDT_REQUIRE(xyz && idx_out, LDT_EARG, "fps: null pointer");
-    return ldt_fps_launch(xyz, B, n, m, idx_out, ST(stream));
+    return ldt_fps_launch(xyz, B, n, m, skip_near_origin, idx_out, ST(stream));
 }
 extern "C" int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_t S, int32_t k,
                        int32_t* idx_out, float* dist_out, void* stream) {

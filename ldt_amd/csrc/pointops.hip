@@ -9,11 +9,15 @@
 
 // ------------------------------------------------------------------------------------------------
 // FPS: one 512-thread workgroup per cloud; points and running min-distances live in registers
-// (PPT points per thread, point k = tid + 512*j), the per-iteration argmax is a wave shuffle
-// reduction + one LDS hop across the 8 waves.  Semantics = the vendored CUDA twin: start at index 0,
-// distances initialised to 1e38, d = (dx*dx + dy*dy) + dz*dz without FMA contraction, running min,
-// argmax; a tie goes to the smaller (k % 512, k / 512)  (sampling.cu:141-158: strict '>' per thread, then a
-// pairwise tree that keeps the lower thread on equality).
+// (PPT points per thread, point k = tid + 512*j).  The per-iteration argmax is a wave shuffle reduction + one LDS hop across
+// the 8 waves, and the winner's COORDINATES travel with (distance, index) through that reduction, so the next iteration starts
+// from LDS — no dependent global load of p[best] on the serial chain (m - 1 iterations; was ~0.6 us of each 1.3 us iteration).
+// Several clouds share a CU (40 VGPRs, 112 B of LDS: four workgroups per CU): launch as many clouds at once as the caller has.
+// Semantics = the vendored CUDA twin: start at index 0, distances initialised to 1e38, d = (dx*dx + dy*dy) + dz*dz without
+// FMA contraction, running min, argmax; a tie goes to the smaller (k % 512, k / 512)  (sampling.cu:141-158: strict '>' per
+// thread, then a pairwise tree that keeps the lower thread on equality).
+// skip_near_origin (default off): the upstream pointnet2_ops kernel the reference actually calls (not vendored)
+// additionally ignores points with |p|^2 <= 1e-3 — they never update their distance and are never selected.
 struct Cand { float d; int k; };
 __device__ __forceinline__ bool beats(float da, int ka, float db, int kb) {
     // both candidates come from the same 512-stride layout: rank = (k & 511, k >> 9)
@@ -23,38 +27,46 @@ __device__ __forceinline__ bool beats(float da, int ka, float db, int kb) {
 }
 
 template <int PPT>
-__global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz, int n, int m, int* __restrict__ idx_out) {
+__global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz, int n, int m, int skip_near_origin, int* __restrict__ idx_out) {
     __shared__ float s_d[8];
     __shared__ int s_k[8];
+    __shared__ float s_c[8][3];
     __shared__ float s_pt[3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = xyz + (long)b * n * 3;
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    bool live[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int k = tid + 512 * j;
         const bool in = k < n;
         px[j] = in ? p[3 * k] : 0.f; py[j] = in ? p[3 * k + 1] : 0.f; pz[j] = in ? p[3 * k + 2] : 0.f;
         dist[j] = 1e38f;
+        float mag;
+        {
+#pragma clang fp contract(off)
+            mag = (px[j] * px[j] + py[j] * py[j]) + pz[j] * pz[j];
+        }
+        live[j] = in && !(skip_near_origin && mag <= 1e-3f);
     }
     if (tid == 0) { idx_out[(long)b * m] = 0; s_pt[0] = p[0]; s_pt[1] = p[1]; s_pt[2] = p[2]; }
     __syncthreads();
     for (int it = 1; it < m; ++it) {
         const float x1 = s_pt[0], y1 = s_pt[1], z1 = s_pt[2];
         float best = -1.f; int besti = 0;
+        float bx = 0.f, by = 0.f, bz = 0.f;
         {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
-                const int k = tid + 512 * j;
-                if (k < n) {
+                if (live[j]) {
                     const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
                     const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
                     const float s = xx + yy;
                     const float d = s + zz;
                     const float d2 = fminf(d, dist[j]);
                     dist[j] = d2;
-                    if (d2 > best) { best = d2; besti = k; }
+                    if (d2 > best) { best = d2; besti = tid + 512 * j; bx = px[j]; by = py[j]; bz = pz[j]; }
                 }
             }
         }
@@ -62,26 +74,28 @@ __global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz,
         for (int o = 32; o > 0; o >>= 1) {
             const float od = __shfl_xor(best, o, 64);
             const int ok = __shfl_xor(besti, o, 64);
-            if (beats(od, ok, best, besti)) { best = od; besti = ok; }
+            const float ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
+            if (beats(od, ok, best, besti)) { best = od; besti = ok; bx = ox; by = oy; bz = oz; }
         }
-        __syncthreads();                     // s_pt consumed by everyone
-        if (lane == 0) { s_d[wave] = best; s_k[wave] = besti; }
-        __syncthreads();
+        if (lane == 0) { s_d[wave] = best; s_k[wave] = besti; s_c[wave][0] = bx; s_c[wave][1] = by; s_c[wave][2] = bz; }
+        __syncthreads();                     // (also: every thread has read s_pt of this iteration)
         if (tid == 0) {
-            float bd = s_d[0]; int bk = s_k[0];
-            for (int w = 1; w < 8; ++w) if (beats(s_d[w], s_k[w], bd, bk)) { bd = s_d[w]; bk = s_k[w]; }
+            float bd = s_d[0]; int bk = s_k[0], bw = 0;
+            for (int w = 1; w < 8; ++w) if (beats(s_d[w], s_k[w], bd, bk)) { bd = s_d[w]; bk = s_k[w]; bw = w; }
             idx_out[(long)b * m + it] = bk;
-            s_pt[0] = p[3 * bk]; s_pt[1] = p[3 * bk + 1]; s_pt[2] = p[3 * bk + 2];
+            // a wave with no live point reports (best = -1, index 0, coordinates 0): index 0 then needs its real coordinates
+            const bool none = bd < 0.f;
+            s_pt[0] = none ? p[0] : s_c[bw][0]; s_pt[1] = none ? p[1] : s_c[bw][1]; s_pt[2] = none ? p[2] : s_c[bw][2];
         }
         __syncthreads();
     }
 }
 
-int ldt_fps_launch(const float* xyz, int B, int n, int m, int* idx, hipStream_t s) {
+int ldt_fps_launch(const float* xyz, int B, int n, int m, int skip_near_origin, int* idx, hipStream_t s) {
     LDT_REQUIRE(B > 0 && n > 0 && m > 0 && m <= n, LDT_ESHAPE, "fps: B=%d n=%d m=%d", B, n, m);
     LDT_REQUIRE(n <= 512 * 16, LDT_ESHAPE, "fps: n=%d > 8192 points per cloud not built", n);
-    if (n <= 512 * 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(512), 0, s, xyz, n, m, idx);
-    else hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(512), 0, s, xyz, n, m, idx);
+    if (n <= 512 * 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(512), 0, s, xyz, n, m, skip_near_origin, idx);
+    else hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(512), 0, s, xyz, n, m, skip_near_origin, idx);
     return ldt_check_launch("fps");
 }
 
@@ -235,6 +249,41 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
     if (lane == 0) { atomicAdd(&stats[2 * b], s1); atomicAdd(&stats[2 * b + 1], s2); }
 }
 
+// 'anchor' statistics, vector form (D % 4 == 0, D / 4 <= 32: the shipped 128- and 64-channel groupers): one wave per group of
+// k neighbour rows; a row is read as 16 B per lane by D/4 lanes (64 / (D/4) rows in flight per wave), the xyz tail by lanes
+// 0..2 of each row group; differences and their squares are summed in fp32 over the <= k/rows-in-flight rows a lane sees
+// (a few dozen terms) and only the per-group totals go through fp64 — the scalar kernel's per-element fp64 converts / adds
+// and its dependent index -> address -> load chain per row were the 611 us (128 clouds) of profiles/r01_c4_*.
+template <int D4>
+__global__ __launch_bounds__(256) void group_stats_vec_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
+                                                              const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
+                                                              int n, int S, int k, double* __restrict__ stats) {
+    constexpr int D = D4 * 4, RPW = 64 / D4;                     // rows in flight per wave
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int sub = lane / D4, l = lane % D4;                    // row slot of this lane, its 4-channel chunk
+    double t1 = 0.0, t2 = 0.0;
+    for (int sidx = blockIdx.x * 4 + (threadIdx.x >> 6); sidx < S; sidx += gridDim.x * 4) {
+        const int ci = fps_idx[(long)b * S + sidx];
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(feat + ((long)b * n + ci) * D + l * 4);
+        const float xa = l < 3 ? xyz[((long)b * n + ci) * 3 + l] : 0.f;
+        const int* nb = knn_idx + ((long)b * S + sidx) * k;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = sub; j < k; j += RPW) {
+            const int pi = nb[j];
+            const f32x4 g = *reinterpret_cast<const f32x4*>(feat + ((long)b * n + pi) * D + l * 4);
+            const float gx = l < 3 ? xyz[((long)b * n + pi) * 3 + l] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = g[r] - fa[r]; s1 += d; s2 = fmaf(d, d, s2); }
+            const float dx = gx - xa;                            // (0 for lanes >= 3)
+            s1 += dx; s2 = fmaf(dx, dx, s2);
+        }
+        t1 += (double)s1; t2 += (double)s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    if (lane == 0) { atomicAdd(&stats[2 * b], t1); atomicAdd(&stats[2 * b + 1], t2); }
+}
+
 template <bool CENTER>
 __global__ __launch_bounds__(256) void group_build_kernel(const float* __restrict__ feat, const float* __restrict__ xyz,
                                                           const int* __restrict__ fps_idx, const int* __restrict__ knn_idx,
@@ -288,7 +337,10 @@ int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, co
         hipLaunchKernelGGL(group_build_kernel<true>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, gmean, n, S, k, D, U, ldu);
         return ldt_check_launch("group_build");
     }
-    hipLaunchKernelGGL(group_stats_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, nullptr, n, S, k, D, stats);
+    int gx = (S + 3) / 4; if (gx > 64) gx = 64;
+    if (D == 128 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<32>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
+    else if (D == 64 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<16>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
+    else hipLaunchKernelGGL(group_stats_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, nullptr, n, S, k, D, stats);
     TRY_LAUNCH("group_stats");
     hipLaunchKernelGGL(group_build_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, nullptr, n, S, k, D, U, ldu);
     return ldt_check_launch("group_build");

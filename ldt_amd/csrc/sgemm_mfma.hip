@@ -56,13 +56,13 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const SgemmArgs a) {
         for (int c = 0; c < CA; ++c) {
             const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
             const int m = m0 + row;
-            ra[c] = (ch < TM * 4 && m < a.M) ? *reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[c] = (ch < TM * 4 && m < a.M && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
             const int n = n0 + row;
-            rb[c] = (ch < TN * 4 && n < a.N) ? *reinterpret_cast<const f32x4*>(a.B + (long)n * a.ldb + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[c] = (ch < TN * 4 && n < a.N && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.B + (long)n * a.ldb + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage = [&]() {
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const SgemmArgs a) {
         }
 }
 
-// -> true when the MFMA kernel took the problem (K % 16 == 0, 16-byte aligned rows); otherwise the caller falls back to the
-// scalar kernel (ragged K: the 3-channel input convs, 131/259-channel grouper rows).
+// -> true when the MFMA kernel took the problem (K % 4 == 0 — a ragged last slab is zero-filled —, 16-byte aligned rows);
+// otherwise the caller falls back to the scalar kernel (the 3-channel input convs, 131/259-channel grouper rows).
 bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status) {
-    if (a->K % SG_BK != 0 || a->lda % 4 != 0 || a->ldb % 4 != 0 || !ldt_aligned16(a->A) || !ldt_aligned16(a->B)) return false;
+    if (a->K % 4 != 0 || a->K < 8 || a->lda % 4 != 0 || a->ldb % 4 != 0 || !ldt_aligned16(a->A) || !ldt_aligned16(a->B)) return false;
     if ((long)a->M * a->N < 64 * 64) return false;       // tiny problems: launch-bound either way, keep the simple kernel
     if (a->M <= 48) {                                     // skinny: per-step per-sample AdaLN rows (M = batch), weight streaming
         dim3 grid((a->N + 255) / 256, (a->M + 31) / 32);

@@ -177,13 +177,20 @@ def philox_normal(shape, device, seed, step=0, elem_offset=0):
 
 
 # ----------------------------------------------------------------------------- Compressor encoder front end
-def fps(xyz, m):
+# Upstream pointnet2_ops (the library the reference calls for FPS; not vendored, not importable here — SURVEY §8c) ignores
+# points with |p|^2 <= 1e-3; the reference's vendored twin (model/functional/src/sampling/sampling.cu) does not.  Default:
+# the twin.  Flip this (or LDT_FPS_SKIP_NEAR_ORIGIN=1, or pass skip_near_origin=) for a real-checkpoint comparison.
+FPS_SKIP_NEAR_ORIGIN = bool(int(__import__("os").environ.get("LDT_FPS_SKIP_NEAR_ORIGIN", "0")))
+
+
+def fps(xyz, m, skip_near_origin=None):
     """xyz fp32 [B,n,3] -> int32 [B,m] (farthest point sampling, start index 0)."""
     _need(xyz, torch.float32, "xyz")
     xyz = xyz.contiguous()
     B, n, _ = xyz.shape
     idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
-    check(lib().ldt_fps(_p(xyz), B, n, m, _p(idx), stream_ptr()), "ldt_fps")
+    skip = FPS_SKIP_NEAR_ORIGIN if skip_near_origin is None else bool(skip_near_origin)
+    check(lib().ldt_fps(_p(xyz), B, n, m, int(skip), _p(idx), stream_ptr()), "ldt_fps")
     return idx
 
 

@@ -84,7 +84,13 @@ class Trainer:
             if self.sample_mode not in ("discrete", "continuous"):
                 raise NotImplementedError("sample_mode %r" % (self.sample_mode,))
             cs = self.cfg.score
-            shape = (cs.z_scale, cs.z_dim + 3 if getattr(cs, "graphconv", False) else cs.z_dim)
+            if getattr(cs, "graphconv", False):
+                # Latent_SDE_Trainer.py:158 samples (z_scale, z_dim + 3) latents under cfg.score.graphconv, which Score.ln_in —
+                # Conv1d(z_dim -> hidden), score.py:110 — then rejects: no shipped YAML sets it; same failure, said plainly
+                raise RuntimeError("cfg.score.graphconv=True: the sampler would draw latents with z_dim + 3 = %d channels, but "
+                                   "Score.ln_in expects z_dim = %d (the reference fails in conv1d on the same mismatch)"
+                                   % (cs.z_dim + 3, cs.z_dim))
+            shape = (cs.z_scale, cs.z_dim)
             rank, ws = ldist.world()
             lo, hi, per = ldist.shard_bounds(num_samples, rank, ws)
             # every rank draws the FULL-batch x0 from its (identically seeded) CPU generator, then keeps its rows

@@ -383,12 +383,15 @@ def compressor_decode(sd, cfg, given_eps, keep_mask=None):
 # ----------------------------------------------------------------------------- Compressor: encode
 
 
-def fps(xyz, m):
+def fps(xyz, m, skip_near_origin=False):
     """Farthest point sampling, restating model/functional/src/sampling/sampling.cu:86-167
     (the vendored twin of pointnet2_ops' kernel; **parity unpinned**, see module header).
     Start index 0; distances init 1e38 (sampling.cpp:53-54); running min; argmax; ties go to the
     smaller (k % 512, k // 512) as the 512-thread strided scan + pairwise tree does (:141-158).
-    Squared distance is (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction."""
+    Squared distance is (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction.
+    skip_near_origin: what upstream pointnet2_ops (the library the reference really calls, model/Compressor/layers.py:106;
+    not vendored — behaviour restated from its published kernel, unverifiable here) does in addition: points with
+    |p|^2 <= 1e-3 neither update their distance nor can be selected (argmax starts from (best = -1, index 0))."""
     xyz = np.ascontiguousarray(xyz.detach().cpu().numpy(), dtype=np.float32)
     b, n, _ = xyz.shape
     out = np.zeros((b, m), dtype=np.int64)
@@ -397,16 +400,22 @@ def fps(xyz, m):
     for bi in range(b):
         p = xyz[bi]
         dist = np.full((n,), np.float32(1e38), dtype=np.float32)
+        live = np.ones((n,), dtype=bool)
+        if skip_near_origin:
+            live = ((p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]) > np.float32(1e-3)
         old = 0
         for j in range(1, m):
             dx = p[:, 0] - p[old, 0]
             dy = p[:, 1] - p[old, 1]
             dz = p[:, 2] - p[old, 2]
             d = (dx * dx + dy * dy) + dz * dz
-            dist = np.minimum(d, dist)
-            best = dist.max()
-            cand = np.nonzero(dist == best)[0]
-            old = int(cand[np.argmin(tie_rank[cand])])
+            dist = np.where(live, np.minimum(d, dist), dist)
+            if not live.any():
+                old = 0
+            else:
+                best = dist[live].max()
+                cand = np.nonzero((dist == best) & live)[0]
+                old = int(cand[np.argmin(tie_rank[cand])])
             out[bi, j] = old
     return torch.from_numpy(out)
 

@@ -43,6 +43,26 @@ def test_fps_ties_and_start(mods):
     assert ops.fps(q.cuda(), 4)[0].tolist() == [0, 4, 1, 3]
 
 
+def test_fps_skip_near_origin(mods):
+    """The upstream pointnet2_ops variant: points with |p|^2 <= 1e-3 are never selected and never update their
+    distance; default stays the vendored twin.  GPU == oracle restatement, both switch positions, many clouds at once."""
+    ops, O = mods
+    g = torch.Generator().manual_seed(4)
+    p = torch.randn(6, 700, 3, generator=g) * 0.4
+    p[:, 5:300:7] *= 0.02                                   # a band of points inside the 1e-3 ball around the origin
+    p[:, 0] = torch.tensor([0.5, 0.1, -0.2])
+    assert int(((p ** 2).sum(-1) <= 1e-3).sum()) > 100
+    for skip in (False, True):
+        ref = O.fps(p, 64, skip_near_origin=skip)
+        out = ops.fps(p.cuda(), 64, skip_near_origin=skip)
+        assert torch.equal(out.cpu().long(), ref)
+    picked = O.gather(p, O.fps(p, 64, skip_near_origin=True))[:, 1:]
+    assert float((picked ** 2).sum(-1).min()) > 1e-3       # none of the skipped points was chosen
+    assert not torch.equal(O.fps(p, 640, skip_near_origin=True), O.fps(p, 640))
+    z = torch.zeros(1, 40, 3)                               # every point skipped: the kernel keeps returning index 0
+    assert ops.fps(z.cuda(), 5, skip_near_origin=True)[0].tolist() == [0, 0, 0, 0, 0] == O.fps(z, 5, skip_near_origin=True)[0].tolist()
+
+
 @pytest.mark.parametrize("B,n,S,k", [(2, 2048, 256, 16), (2, 2048, 32, 128), (2, 64, 8, 16), (1, 300, 7, 5), (1, 5000, 10, 64)])
 def test_knn_sets(mods, B, n, S, k):
     ops, O = mods

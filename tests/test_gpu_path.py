@@ -255,6 +255,21 @@ def test_decoder_golden(env):
     assert torch.equal(pts, pts2)
 
 
+def test_decoder_keep_mask_golden(env):
+    """Compressor.sample((B, n), ...) with n < max_outputs vs the reference: explicit keep_mask, and the reference's own
+    randperm stream from a seeded CPU generator (`reference_rng`)."""
+    a, _ = load_golden("decoder_keepmask")
+    comp, n = env["comp"], int(a["num_points"])
+    B = a["given_eps"].shape[0]
+    pts = comp.sample((B, n), given_eps=a["given_eps"].cuda(), keep_mask=a["keep_mask"])
+    assert pts.shape == (B, n, 3) and rel_mse(pts.cpu(), a["points"]) < TOL_DECODE
+    torch.manual_seed(int(a["seed"]))
+    pts2 = comp.sample((B, n), given_eps=a["given_eps"].cuda())      # draws B randperms exactly like sample_mask
+    assert torch.equal(pts2, pts)
+    other = comp.sample((B, n), given_eps=a["given_eps"].cuda(), keep_mask=a["keep_mask"].roll(1, 1))
+    assert rel_mse(other.cpu(), a["points"]) > 1e-3                  # (the subset matters)
+
+
 def test_philox_sampling_is_seeded_and_shard_invariant(env):
     """Device-noise mode: same seed -> same shapes; a batch of 4 == two shards of 2 with sample_offset."""
     tr, cfg = env["tr"], env["cfg"]

@@ -264,3 +264,15 @@ def test_gelu_epilogue_form_accuracy():
     small = np.abs(x) < 1e4
     assert np.abs(y[small] - ref[small]).max() <= 1e-6
     assert np.allclose(y[~small], ref[~small], rtol=1e-6)
+
+
+def test_graphconv_is_rejected_like_the_reference(tiny_cfg):
+    """cfg.score.graphconv=True makes the reference sample (z_scale, z_dim + 3) latents (Latent_SDE_Trainer.py:158) that its own
+    Score.ln_in (Conv1d z_dim -> hidden) rejects; the build raises the same kind of error before touching the GPU."""
+    import copy
+    import ldt_amd
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.score.graphconv = True
+    tr = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor), "cpu")
+    with pytest.raises(RuntimeError, match="graphconv"):
+        tr.sample(2)

@@ -178,6 +178,19 @@ def test_decoder(tiny_cfg):
     assert rel_mse(out, a["points"]) < TOL
 
 
+def test_decoder_keep_mask(tiny_cfg):
+    """num_points < max_outputs: InitialSet keeps the prior rows whose randperm rank is below num_points, in index order
+    (model/Compressor/ops.py:6-14, layers.py:31-34)."""
+    a, _ = load_golden("decoder_keepmask")
+    sd = load_golden("trainer_sample_tiny")[1]["c"]
+    assert int(a["keep_mask"].sum(1).min()) == int(a["num_points"]) == int(a["keep_mask"].sum(1).max())
+    out = O.compressor_decode(sd, tiny_cfg.compressor, a["given_eps"], keep_mask=a["keep_mask"])
+    assert out.shape == a["points"].shape and rel_mse(out, a["points"]) < TOL
+    torch.manual_seed(int(a["seed"]))                               # the recorded draws are what a seeded CPU generator yields
+    perms = torch.stack([torch.randperm(tiny_cfg.compressor.max_outputs) for _ in range(a["perms"].shape[0])])
+    assert torch.equal(perms, a["perms"])
+
+
 def test_encoder(tiny_cfg):
     a, _ = load_golden("compressor_fwd_tiny")
     sd = load_golden("trainer_sample_tiny")[1]["c"]
