@@ -252,7 +252,7 @@ def _timed(fn, reps=2):
     return (time.perf_counter() - t0) / reps, r
 
 
-def extra_c4(tokens=256, batch=1024, chunk=128):
+def extra_c4(tokens=256, batch=1024, chunk=1024):
     """BASELINE configs[3]: Compressor encode + decode only (2048 -> T tokens -> 2048), batch 1024, 1 GPU, and the
     cross-attention kernel on its own in both orientations.  CPU baseline: the oracle on a bounded sample of clouds."""
     import ldt_amd

@@ -780,10 +780,15 @@ extern "C" int ldt_dbg_gemm_epi(int32_t bits) { g_dbg_epi.store(bits); return LD
 
 template <int EPI, int FOLD = FOLD_NONE, int PRE = 0>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
-    static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : 1;
+    // Tile order: wide outputs (QKV: 12 column tiles, MLP-up: 16) are swept in groups of 8 row panels, so an XCD's 32
+    // workgroups hold an 8 x 4 block of tiles (8 X panels + 4 W panels live in its 4 MiB L2) instead of 2 x 16 — the W panel
+    // set is then re-streamed from the fabric once per 8 row panels, not once per 2 (profiles/: MLP-up fetched 2.5x its
+    // unique bytes in row-major order).  Speed: QKV +1.6 %, others equal (tools/dbg/gm_bench.py).  LDT_GEMM_GM overrides.
+    static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;
     const int gm_dbg = g_group_m.load();
     GemmArgs a_copy = *a_in;
-    a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env;
+    const int tn = (a_in->N + 255) / 256, tm = (a_in->M + 255) / 256;
+    a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
     static const int dbg_env = getenv("LDT_DBG_EPI") ? atoi(getenv("LDT_DBG_EPI")) : 0;
     a_copy.dbg = g_dbg_epi.load() >= 0 ? g_dbg_epi.load() : dbg_env;
     const GemmArgs* a = &a_copy;
@@ -858,7 +863,9 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     // sub-batch stream's share): at exactly half (M = 8192, N = 1024: 128 tiles on 256 CUs) the 128^2 kernel on every CU
     // is as fast (K = 1024) or 15 % faster (K = 4096).
     const int lim256 = (a->max_wgs > 0 && a->max_wgs < LDT_NUM_CUS) ? a->max_wgs : LDT_NUM_CUS;
-    if ((force == 256 || (force == 0 && tiles256 * 8 >= lim256 * 5)) && a->M >= 16 && a->N >= 16) {
+    // (N <= 128 — the Compressor's 128-channel convs over millions of point rows — would leave half of every 256-wide tile
+    //  empty: the 128^2 kernel streams those 5.7 % faster end to end, tools/dbg/c4_chunks.py)
+    if ((force == 256 || (force == 0 && tiles256 * 8 >= lim256 * 5 && a->N > 128)) && a->M >= 16 && a->N >= 16) {
         switch (epi) {
             case EPI_F32: return launch_256<EPI_F32>(a, stream);
             case EPI_BF16: return launch_256<EPI_BF16>(a, stream);

@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--tokens", type=int, default=256)
-    ap.add_argument("--chunk", type=int, default=128, help="clouds per encode pass")
+    ap.add_argument("--chunk", type=int, default=1024, help="clouds per encode pass (one call for the whole batch measured fastest)")
     ap.add_argument("--reps", type=int, default=2)
     a = ap.parse_args()
     import ldt_amd
