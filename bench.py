@@ -161,7 +161,9 @@ def roofline_pass(trainer, cfg, B, reps=3):
         if name in hbm_bytes:
             k["gbps"] = round(hbm_bytes[name] / (avg * 1e-3) / 1e9, 1)
         kernels[name] = k
-        sym = ("gemm_bf16_nt_256_kernel<%d, %d>" % (epi_id[name], fold_id[name] if folded else 0)) if name in epi_id else \
+        # rocprofv3 symbol: <epilogue id, LN folding (1 producer, 2 consumer), residual rows through the operand ring (one tile per workgroup)>
+        xr = 1 if name in ("gemm_o", "gemm_dn") and (M // 256) * (D // 256) <= 256 and M % 256 == 0 else 0
+        sym = ("gemm_bf16_nt_256_kernel<%d, %d, %d>" % (epi_id[name], fold_id[name] if folded else 0, xr)) if name in epi_id else \
             {"attention": "attn_fwd_kernel<64, false>", "ln_modulate": "ln_mod_vec_kernel<4>"}.get(name)
         if sym is None:
             continue

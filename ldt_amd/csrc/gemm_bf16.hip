@@ -344,33 +344,17 @@ __device__ __forceinline__ void v2_fold_finalize(char* stage_base, int R, int pa
 }
 
 // interior tiles: per-wave LDS staging (16 output rows per pass) -> 16 B per lane over whole rows
-// ---- PRE: the fp32 residual tile read during the main loop (see the kernel's header comment) ----------------------------
-// |gate| below this is replaced by +-V2_GATE_MIN where the residual rides the accumulators scaled by 1/gate: the term it
-// multiplies is then <= 1e-20 |acc + bias|, far below one ulp of x
-#define V2_GATE_MIN 1e-20f
-__device__ __forceinline__ float v2_gate_safe(float g) { return fabsf(g) < V2_GATE_MIN ? __builtin_copysignf(V2_GATE_MIN, g) : g; }
-// Three 1 KiB landing slots at the head of the wave's staging area (idle during the main loop): a fragment is fetched by
-// LDS-DMA like the operand sub-tiles — no VGPR holds it in flight, hipcc counts the op in vmcnt but never waits on it — and
-// read back (ds_read_b128, lane-linear) when it is folded into the accumulators.
-template <int SLOT>
-__device__ __forceinline__ void v2_pre_load(const char* p, char* stage_reg) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                     (__attribute__((address_space(3))) void*)(stage_reg + SLOT * 1024), 16, 0, 0);
-}
-// fragment J = (ni = J & 3, mi = J >> 2) of the residual tile, scaled by 1/gate of its 4 columns, into its accumulator tile
-template <int J>
-__device__ __forceinline__ void v2_pre_add(f32x4 (&acc)[4][8], const char* stage_reg, const char* ginv_lds, int lane, int lchk) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(stage_reg + (J % 3) * 1024 + lane * 16);
-    const f32x4 gi = *reinterpret_cast<const f32x4*>(ginv_lds + ((J & 3) * 16 + lchk * 4) * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[J & 3][J >> 2][r] = fmaf(x[r], gi[r], acc[J & 3][J >> 2][r]);
-    asm volatile("" : "+v"(acc[J & 3][J >> 2]));                     // done here, in the MFMA shadow (not floated past the barrier into a load segment)
-}
-
-template <int EPI, int FOLD, int PRE = 0>
+// XRING (EPI_RESID_F32 on a workgroup's LAST tile, batch-shared gate): the fp32 residual rows are not loaded pass by pass into
+// VGPRs (4 x 16 B per lane in flight per wave = 32 KB per CU: at ~2.5 us of HBM latency that caps the read at ~3.3 TB/s
+// chip-wide, 18-21 us of exposed epilogue — tools/dbg/epi_ablate.py) but by LDS-DMA into the operand ring, which is idle by
+// then: `xring` = this wave's 16 KiB of it = four 4 KiB pass slots.  Passes 0..3 are requested up front, pass mi + 4 when
+// pass mi has consumed its slot: 16 KB per wave (128 KB per CU) in flight, lane-linear both ways (a lane reads back the 16 B it
+// requested).  Counted waits: vmcnt(N), N = the ops issued after pass mi's requests (later requests + SP stores per pass).
+template <int EPI, int FOLD, int XRING = 0>
 __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
                                                    int lane, int lrow, int lchk, const float* gate, char* reg, char* stage_base,
-                                                   const float* ln_scale, bool have_pre, f32x4 g4_pre, f32x4 sc4_pre) {
+                                                   const float* ln_scale, bool have_pre, f32x4 g4_pre, f32x4 sc4_pre,
+                                                   char* xring = nullptr) {
     const int mb = m0 + grp * 128, nb = n0 + wn * 64;
     f32x4 bias4[4];
 #pragma unroll
@@ -438,13 +422,26 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
         f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
         const bool has_gate = (EPI == EPI_RESID_F32) && gate;
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
-        if (PRE) g4 = *reinterpret_cast<const f32x4*>(reg + V2_SC_OFF + 256 + ch * 16);      // clamped gate, stashed at tile start
-        else if (shared_gate) g4 = have_pre ? g4_pre : *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
+        if (shared_gate) g4 = have_pre ? g4_pre : *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
+        constexpr int SP = (FOLD == FOLD_PRODUCER) ? 8 : 4;       // VMEM stores a pass issues (x, and xs for the producer)
+        // running source pointer: row (lane>>4) of the next 4-row group, advanced 4 rows per request (passes are requested in
+        // order 0..7); kept opaque so that hipcc does not materialise all 32 addresses up front
+        const float* xsrc = XRING ? a.resid + ((long)mb + (lane >> 4)) * a.ldr + nb + ch * 4 : nullptr;
+        const long xstep = (long)4 * a.ldr;
+        auto request_pass = [&](int p) {                          // 4 x 1 KiB: rows it*4 + (lane>>4) of pass p, 16 B per lane
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                                 (__attribute__((address_space(3))) void*)(xring + (p & 3) * 4096 + it * 1024), 16, 0, 0);
+                xsrc += xstep;
+                asm volatile("" : "+v"(xsrc));
+            }
+        };
+        if (XRING) { request_pass(0); request_pass(1); request_pass(2); request_pass(3); }
         float rs1[8], rs2[8];                                     // FOLD_PRODUCER: lanes with (lane & 15) < 4 keep row (lane&15)*4 + (lane>>4) of pass mi
         if (FOLD == FOLD_PRODUCER) {
-            const f32x4 t = PRE ? *reinterpret_cast<const f32x4*>(reg + V2_SC_OFF + 512 + ch * 16)
-                                : have_pre ? sc4_pre : *reinterpret_cast<const f32x4*>(ln_scale + nb + ch * 4);
+            const f32x4 t = have_pre ? sc4_pre : *reinterpret_cast<const f32x4*>(ln_scale + nb + ch * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc4[r] = 1.0f + t[r];
         }
@@ -459,14 +456,28 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
             }
             const long mrow0 = mb + mi * 16;
             float k1 = 0.f, k2 = 0.f;
+            if (XRING) {                                             // pass mi's rows have landed (ops issued after its requests: see above)
+                constexpr int NW[8] = {12, 12 + SP, 12 + 2 * SP, 12 + 3 * SP, 12 + 3 * SP, 8 + 3 * SP, 4 + 3 * SP, 3 * SP};
+                switch (mi) {                                        // (mi is a compile-time constant of the unrolled loop)
+                    case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[0]) : "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[1]) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[2]) : "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[3]) : "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[4]) : "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[5]) : "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[6]) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW[7]) : "memory"); break;
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + (lane >> 4);
                 f32x4 v = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((ch ^ row) << 4));
                 float* o = reinterpret_cast<float*>(a.out) + (mrow0 + row) * a.ldo + nb + ch * 4;
-                if (EPI == EPI_RESID_F32 && PRE) {                   // x already sits in the accumulators as x / gate
+                if (EPI == EPI_RESID_F32 && XRING) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(xring + (mi & 3) * 4096 + it * 1024 + lane * 16);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = g4[r] * v[r];
+                    for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                 } else if (EPI == EPI_RESID_F32) {
                     f32x4 x = {0.f, 0.f, 0.f, 0.f};
                     if (!(a.dbg & 1)) x = *reinterpret_cast<const f32x4*>(a.resid + (mrow0 + row) * a.ldr + nb + ch * 4);
@@ -475,10 +486,10 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                 }
-                if ((EPI != EPI_DISCARD || a.M < 0) && !(a.dbg & 2)) *reinterpret_cast<f32x4*>(o) = v;
+                if ((EPI != EPI_DISCARD || a.M < 0) && (XRING || !(a.dbg & 2))) *reinterpret_cast<f32x4*>(o) = v;
                 if (FOLD == FOLD_PRODUCER) {
                     const bf16x4 pk = {(bf16_t)(v[0] * sc4[0]), (bf16_t)(v[1] * sc4[1]), (bf16_t)(v[2] * sc4[2]), (bf16_t)(v[3] * sc4[3])};
-                    if (!(a.dbg & 4)) *reinterpret_cast<bf16x4*>(a.xs + (mrow0 + row) * a.ldxs + nb + ch * 4) = pk;
+                    if (XRING || !(a.dbg & 4)) *reinterpret_cast<bf16x4*>(a.xs + (mrow0 + row) * a.ldxs + nb + ch * 4) = pk;
                     const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                     const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
                     const bool keep = (lane & 15) == it;
@@ -486,6 +497,7 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
                 }
             }
             rs1[mi] = k1; rs2[mi] = k2;
+            if (XRING && mi < 4) request_pass(mi + 4);               // into the slot this pass has just consumed
         }
         if (FOLD == FOLD_PRODUCER && !(a.dbg & 8)) {
             // the wave's 128 rows x (sum, sumsq) over its 64 columns -> head of its staging area; the four column waves of a
@@ -509,16 +521,9 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
     }
 }
 
-// PRE = 1 (EPI_RESID_F32, batch-shared gate, K >= 1024, whole aligned tiles): the fp32 residual tile is not read in the
-// epilogue — measured on rotating cold buffers, 18-21 us of a residual GEMM's 32 us epilogue are that read, fully exposed
-// (one tile per CU, MFMA idle, every CU bursting at once) — but during the LAST 32 sub-tiles of the main loop: one
-// 16-B-per-lane load in accumulator-fragment layout per sub-tile (issued in the slack after a phase's MFMAs), folded into
-// its accumulator tile two to three sub-tiles later as acc += x * (1/gate).  With the gate a per-column constant,
-// gate * (acc + x/gate + bias) = x + gate * (acc + bias): fp32 throughout, ~2 ulp of x for the detour through 1/gate.
-// The accumulator tile a fragment belongs to must be a compile-time index: those 32 sub-tiles are 32
-// unrolled instances of the sub-tile body.  The loads sit in the in-order VMEM queue between the DMA batches, whose counted
-// waits look past the two newest of them (vmcnt 8).
-template <int EPI, int FOLD = FOLD_NONE, int PRE = 0>
+// XRING = 1 (EPI_RESID_F32, one tile per workgroup — launcher): the epilogue fetches the fp32 residual rows through the idle
+// operand ring (v2_epilogue_staged).
+template <int EPI, int FOLD = FOLD_NONE, int XRING = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x;
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
     f32x4 g4_pre = {1.f, 1.f, 1.f, 1.f}, sc4_pre = {0.f, 0.f, 0.f, 0.f};
     const bool pre_ok = (EPI == EPI_RESID_F32) && gate && a.gate_sample_stride == 0;
-    if (EPI == EPI_RESID_F32 && !PRE) {
+    if (EPI == EPI_RESID_F32) {
         int m0, n0;
         tile_of(0, m0, n0);
         if (n0 + 256 <= a.N) {
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
     ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx);   // X0 W0 X1 W1 X2
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     // sub-tile 0 landed
     V2_BARRIER();
-    if (EPI == EPI_RESID_F32 && !PRE)                                    // (older than every DMA above: already retired)
+    if (EPI == EPI_RESID_F32)                                            // (older than every DMA above: already retired)
         asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
 
     // per-lane LDS read offsets inside a ring slot: row*64 + ((chunk ^ f(row)) << 4)
@@ -648,28 +653,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
         enum { ST_PLAIN = 0, ST_FIRST = 1 /* first wait allows for the previous epilogue's stores */, ST_CHECK_FIRST = 2 /* runtime v == 0 */,
                ST_FOLD_DMA = 4 /* fetch this tile's row statistics + S | C slices */, ST_FOLD_FINAL = 8 /* (rstd, -mean rstd) per row */ };
         int v = 0;
-        // PRE: this lane's pointer to the next residual fragment (row lrow of its row group, 4 columns at lchk*4 of its
-        // 64-column strip; fragments advance ni fastest), and the per-column vectors of the tile stashed in the tail of the
-        // wave's staging area (free until the epilogue's first pass, which reads gate / ln_scale back before it stages)
-        const char* rp = nullptr;
-        const long rp_row = PRE ? (long)16 * a.ldr * 4 - 192 : 0;       // from (ni = 3, mi) to (ni = 0, mi + 1)
-        const char* ginv_lds = stage_reg + V2_SC_OFF;
-        if (PRE) {
-            rp = reinterpret_cast<const char*>(a.resid + ((long)m0 + grp * 128 + lrow) * a.ldr + n0 + wn * 64 + lchk * 4);
-            const float gv = v2_gate_safe(gate ? gate[n0 + wn * 64 + lane] : 1.0f);
-            *reinterpret_cast<float*>(stage_reg + V2_SC_OFF + lane * 4) = 1.0f / gv;
-            *reinterpret_cast<float*>(stage_reg + V2_SC_OFF + 256 + lane * 4) = gv;
-            if (FOLD == FOLD_PRODUCER) *reinterpret_cast<float*>(stage_reg + V2_SC_OFF + 512 + lane * 4) = ln_scale[n0 + wn * 64 + lane];
-        }
-        // RK >= 0 (PRE, the tile's last 32 sub-tiles, unrolled): after phase 0's MFMAs this sub-tile folds fragment RK-3 when it
-        // belongs to an accumulator tile mi >= 4 (idle there) and requests fragment RK into the slot that frees; after phase 1's
-        // MFMAs (and this sub-tile's counted wait, which retires fragment RK-2) it folds RK-2 when that belongs to mi <= 3
-        auto subtile = [&](auto flags_c, auto rk_c) {
+        auto subtile = [&](auto flags_c) {
             constexpr int FL = decltype(flags_c)::value;
-            constexpr int RK = decltype(rk_c)::value;
-            int slot_off = (g & 3) * V2_STAGE_BYTES;
-            if (PRE) asm volatile("" : "+s"(slot_off));                  // unrolled sub-tiles: keep each one's LDS addresses local (merged
-            const char* st = smem2 + slot_off;                           // across sub-tiles they stay live: +48 VGPRs)
+            const char* st = smem2 + (g & 3) * V2_STAGE_BYTES;
             bf16x8 wf[4], xf[4];
             // ---------------- phase 0: W (4 n-tiles) + X (m-tiles 0..3); DMA: W of stream position g+2 ----------------
 #pragma unroll
@@ -702,12 +688,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if constexpr (RK >= 3 && ((RK - 3) >> 2) >= 4) v2_pre_add<(RK >= 3 ? RK - 3 : 0)>(acc, stage_reg, ginv_lds, lane, lchk);
-            if constexpr (RK >= 0) {                                     // request fragment RK (its slot's previous tenant RK-3 is folded)
-                if (!(a.dbg & 16)) v2_pre_load<RK % 3>(rp, stage_reg);
-                rp += ((RK & 3) == 3) ? rp_row : 64;
-                asm volatile("" : "+v"(rp));                             // (keeps hipcc from materialising all 32 addresses up front)
-            }
             V2_BARRIER();
             // ---------------- phase 1: X (m-tiles 4..7); DMA: X of stream position g+3; counted wait ----------------
 #pragma unroll
@@ -716,12 +696,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
             next_x(sx);
             // position g+1 has landed once all but the 3 newest batches (+ a preceding epilogue's stores) retired
             // (an edge epilogue issues a data-dependent number of stores: fall back to the always-safe vmcnt(6))
-            // (PRE: the fragment requested after this sub-tile's phase 0 and the one before it sit between the batches: one
-            //  more op each to look past — the older of the two then has ~2.4 sub-tiles to arrive from HBM before it gates a wait)
-            constexpr int NEWER = 6 + (RK >= 0 ? 1 : 0) + (RK >= 1 ? 1 : 0);
-            if (((FL & ST_FIRST) || ((FL & ST_CHECK_FIRST) && v == 0)) && prev_staged)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER + EPI_VMEM > 63 ? 63 : NEWER + EPI_VMEM) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+            if (((FL & ST_FIRST) || ((FL & ST_CHECK_FIRST) && v == 0)) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + EPI_VMEM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -730,40 +706,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if constexpr (RK >= 2 && ((RK - 2) >> 2) <= 3) v2_pre_add<(RK >= 2 ? RK - 2 : 0)>(acc, stage_reg, ginv_lds, lane, lchk);
             V2_BARRIER();
             ++g;
         };
 #define SUBT(f) std::integral_constant<int, (f)>{}
-#define NOR std::integral_constant<int, -1>{}
         if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 8 sub-tiles
-            subtile(SUBT(ST_FIRST), NOR); subtile(SUBT(ST_PLAIN), NOR); subtile(SUBT(ST_FOLD_DMA), NOR);
-            for (v = 3; v < 6; ++v) subtile(SUBT(ST_PLAIN), NOR);
-            subtile(SUBT(ST_FOLD_FINAL), NOR);
-            for (v = 7; v < nks; ++v) subtile(SUBT(ST_PLAIN), NOR);
-        } else if (PRE) {                                                // K >= 1024 (launcher): the last 32 sub-tiles carry the residual
-            for (v = 0; v < nks - 32; ++v) subtile(SUBT(ST_CHECK_FIRST), NOR);
-            subtile(SUBT(ST_CHECK_FIRST), SUBT(0)); ++v;
-#define R4(b) subtile(SUBT(ST_PLAIN), SUBT(b)); subtile(SUBT(ST_PLAIN), SUBT(b + 1)); subtile(SUBT(ST_PLAIN), SUBT(b + 2)); subtile(SUBT(ST_PLAIN), SUBT(b + 3));
-            subtile(SUBT(ST_PLAIN), SUBT(1)); subtile(SUBT(ST_PLAIN), SUBT(2)); subtile(SUBT(ST_PLAIN), SUBT(3));
-            R4(4) R4(8) R4(12) R4(16) R4(20) R4(24) R4(28)
-#undef R4
+            subtile(SUBT(ST_FIRST)); subtile(SUBT(ST_PLAIN)); subtile(SUBT(ST_FOLD_DMA));
+            for (v = 3; v < 6; ++v) subtile(SUBT(ST_PLAIN));
+            subtile(SUBT(ST_FOLD_FINAL));
+            for (v = 7; v < nks; ++v) subtile(SUBT(ST_PLAIN));
         } else {
-            for (v = 0; v < nks; ++v) subtile(SUBT(ST_CHECK_FIRST), NOR);
+            for (v = 0; v < nks; ++v) subtile(SUBT(ST_CHECK_FIRST));
         }
-#undef NOR
 #undef SUBT
-        if (PRE) {
-            // fragments 29..31 (mi = 7, written by the last MFMAs: let those drain) once every load has landed
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-            v2_pre_add<29>(acc, stage_reg, ginv_lds, lane, lchk); v2_pre_add<30>(acc, stage_reg, ginv_lds, lane, lchk);
-            v2_pre_add<31>(acc, stage_reg, ginv_lds, lane, lchk);
-        }
         if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
 
         prev_staged = (m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned;
-        if (prev_staged || FOLD != FOLD_NONE || PRE)                     // FOLD / PRE: the launcher admits interior, aligned tiles only
-            v2_epilogue_staged<EPI, FOLD, PRE>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
+        if (XRING) {
+            // XRING kernel (one tile per workgroup: launcher): the residual rows arrive through the now idle operand ring —
+            // every wave's outstanding batches must have landed first, and every wave must be past its last ring read
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V2_BARRIER();
+            // (one tile per workgroup: the gate / ln_scale vectors fetched before the main loop are this tile's — no load may
+            //  follow the ring requests, hipcc would wait for it with vmcnt(0) and with it for all sixteen requests)
+            v2_epilogue_staged<EPI, FOLD, 1>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
+                                                true, g4_pre, sc4_pre, smem2 + wave * 16384);
+        } else if (prev_staged || FOLD != FOLD_NONE)                     // FOLD: the launcher admits interior, aligned tiles only
+            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
                                           it == 0 && (pre_ok || FOLD == FOLD_PRODUCER), g4_pre, sc4_pre);
         else v2_epilogue_edge<EPI>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
     }
@@ -778,7 +747,7 @@ extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LD
 static std::atomic<int> g_dbg_epi{-1};
 extern "C" int ldt_dbg_gemm_epi(int32_t bits) { g_dbg_epi.store(bits); return LDT_OK; }   // tools/dbg/epi_ablate.py
 
-template <int EPI, int FOLD = FOLD_NONE, int PRE = 0>
+template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     // Tile order: wide outputs (QKV: 12 column tiles, MLP-up: 16) are swept in groups of 8 row panels, so an XCD's 32
     // workgroups hold an 8 x 4 block of tiles (8 X panels + 4 W panels live in its 4 MiB L2) instead of 2 x 16 — the W panel
@@ -789,27 +758,28 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     GemmArgs a_copy = *a_in;
     const int tn = (a_in->N + 255) / 256, tm = (a_in->M + 255) / 256;
     a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
+    // residual rows of a one-tile workgroup through the operand ring (v2_epilogue_staged XRING, kernel <.., .., 1>): needs the exact VMEM op
+    // count of the epilogue (no per-sample gate loads, no debug skips) and 16-B aligned rows.  LDT_RESID_RING=0: A/B runs.
+    static const bool xring_on = !(getenv("LDT_RESID_RING") && atoi(getenv("LDT_RESID_RING")) == 0);
+    const bool xring = (EPI == EPI_RESID_F32 && xring_on && a_in->resid && a_in->ldr % 4 == 0 && ldt_aligned16(a_in->resid) &&
+                        (!a_in->gate || a_in->gate_sample_stride == 0) && a_in->M % 256 == 0 && a_in->N % 256 == 0 && a_in->ldo % 8 == 0);
     static const int dbg_env = getenv("LDT_DBG_EPI") ? atoi(getenv("LDT_DBG_EPI")) : 0;
     a_copy.dbg = g_dbg_epi.load() >= 0 ? g_dbg_epi.load() : dbg_env;
     const GemmArgs* a = &a_copy;
-    LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD, PRE>), V2_LDS_BYTES, "gemm256");
+    LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256");
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;
     const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
-    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD, PRE>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+    if constexpr (EPI == EPI_RESID_F32) {
+        if (xring && grid == tiles && a->dbg == 0) {                     // every workgroup has exactly one tile: the ring is idle in its epilogue
+            LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256");
+            hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+            return ldt_check_launch("gemm_bf16_nt_256");
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256");
-}
-
-// Residual read folded into the main loop (PRE): whole aligned 256x256 tiles, K >= 1024, one gate vector for every row.
-// OFF by default (LDT_RESID_IN_LOOP=1 enables it): measured on MI355X (tools/dbg/pre_ab.py, epi_ablate.py) the fragment loads
-// stall the main loop by 15 of the 18 us they save — VMEM returns in order, so every operand DMA batch queued behind a fragment
-// inherits its HBM latency (2.5-3 us with all 256 CUs reading, against a ring that covers 2 us) — fc_o 71 -> 67.5 us, mlp.out
-// 146 -> 143 us in isolation, +-1.5 % per SDE step in a forward depending on the box.  Kept as the measured record of the idea.
-static bool v2_resid_in_loop(const GemmArgs* a) {
-    static const bool on = getenv("LDT_RESID_IN_LOOP") && atoi(getenv("LDT_RESID_IN_LOOP")) != 0;
-    return on && a->resid && a->K >= 1024 && a->K % 32 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 && a->ldr % 4 == 0 &&
-           ldt_aligned16(a->resid) && (!a->gate || a->gate_sample_stride == 0);
 }
 
 // LN-folding launches: always the 256-tile kernel, interior + aligned tiles only (checked here, assumed by the kernel).
@@ -827,7 +797,6 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
         LDT_REQUIRE(a->xs && a->ln_scale && a->stats_out && a->ldxs % 4 == 0 && a->ldxs >= a->N && ldt_aligned16(a->xs) &&
                     ldt_aligned16(a->ln_scale) && a->ln_step_stride % 4 == 0 && ldt_aligned16(a->stats_out), LDT_EARG,
                     "gemm_lnfold: producer needs xs / ln_scale / stats_out (16-byte aligned)");
-        if (v2_resid_in_loop(a)) return launch_256<EPI_RESID_F32, FOLD_PRODUCER, 1>(a, stream);
         return launch_256<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
     }
     LDT_REQUIRE(epi == EPI_BF16 || epi == EPI_GELU_BF16, LDT_EARG, "gemm_lnfold: epilogue %d has no folded form", epi);
@@ -871,7 +840,7 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
             case EPI_BF16: return launch_256<EPI_BF16>(a, stream);
             case EPI_GELU_BF16: return launch_256<EPI_GELU_BF16>(a, stream);
             case EPI_RELU_BF16: return launch_256<EPI_RELU_BF16>(a, stream);
-            case EPI_RESID_F32: return v2_resid_in_loop(a) ? launch_256<EPI_RESID_F32, FOLD_NONE, 1>(a, stream) : launch_256<EPI_RESID_F32>(a, stream);
+            case EPI_RESID_F32: return launch_256<EPI_RESID_F32>(a, stream);
             case EPI_DISCARD: return launch_256<EPI_DISCARD>(a, stream);   // timing-only (tools/dbg): no stores
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }

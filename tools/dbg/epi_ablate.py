@@ -1,4 +1,5 @@
-"""Where does the residual GEMM's epilogue time go?  LN-fold producer (fc_o: K=1024, mlp.out: K=4096) at M=16384 with parts of
+"""(any non-zero knob also switches the ring-landed residual read off: the numbers attribute the plain epilogue)
+Where does the residual GEMM's epilogue time go?  LN-fold producer (fc_o: K=1024, mlp.out: K=4096) at M=16384 with parts of
 the epilogue switched off (ldt_dbg_gemm_epi bits), on rotating cache-cold buffers."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,7 +10,7 @@ torch.manual_seed(0)
 NB = 6
 outs = [torch.randn(M, N, device="cuda") for _ in range(NB)]
 gate = torch.randn(N, device="cuda"); sc = torch.randn(N, device="cuda") * 0.1; b = torch.randn(N, device="cuda")
-variants = [("full", 0), ("PRE: fragment loads off (16)", 16), ("PRE: loads off + no stores (22)", 22), ("no-resid-read", 1), ("no-x-store", 2), ("no-xs-store", 4), ("no-stats", 8), ("no-read,no-xs,no-stats", 13),
+variants = [("full", 0), ("no-resid-read", 1), ("no-x-store", 2), ("no-xs-store", 4), ("no-stats", 8), ("no-read,no-xs,no-stats", 13),
             ("stores only off (2|4)", 6), ("nothing (15)", 15)]
 for K in (1024, 4096):
     xs_in = [(torch.randn(M, K, device="cuda") * 0.05).to(torch.bfloat16) for _ in range(NB)]

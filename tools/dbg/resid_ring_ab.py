@@ -1,4 +1,4 @@
-"""A/B of the residual-in-main-loop form (PRE) of the residual GEMMs: child processes with LDT_RESID_IN_LOOP=1/0 alternate
+"""A/B of the ring-landed residual read in the residual GEMMs' epilogue: child processes with LDT_RESID_RING=1/0 alternate
 (the switch is read once per process); cold rotating buffers, LN-fold producer at fc_o (K=1024) and mlp.out (K=4096) shapes,
 plus the whole forward per SDE step."""
 import os, subprocess, sys
@@ -39,5 +39,5 @@ print("  sample(64), 40 steps: %%.3f ms per SDE step" %% ((time.perf_counter() -
 ''' % ROOT
 for rnd in range(2):
     for flag in ("1", "0"):
-        print("LDT_RESID_IN_LOOP=%s" % flag, flush=True)
-        subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, LDT_RESID_IN_LOOP=flag), check=True)
+        print("LDT_RESID_RING=%s" % flag, flush=True)
+        subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, LDT_RESID_RING=flag), check=True)
