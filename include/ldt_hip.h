@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 8
+#define LDT_ABI_VERSION 9
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -171,6 +171,13 @@ int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float*
  *   (Network.py:26-29,75-77); mu_out/logvar_out nullable.
  * ldt_chamfer: distChamfer (evaluation/evaluation_metrics.py:23-33): dl[b][nb] = min over a, dr[b][na] = min over b. */
 int ldt_fps(const float* xyz, int32_t B, int32_t n, int32_t m, int32_t skip_near_origin, int32_t* idx_out, void* stream);
+/* ldt_norm_points: Compressor.norm_pts (Network.py:170-174; cfg.compressor.norm_input): per cloud and coordinate (p - mean) / std,
+ *   unbiased std over the n points; out may alias xyz.
+ * ldt_mixture_seed: InitialSet with max_outputs None (Compressor/layers.py:17-24,38-41): out[r][d] = sum_m (eps[r][m][d] sig[m][d] +
+ *   mu[m][d]) softmax(logits)[m] over rows r = b*N + n; the `output` MLP that follows is two ldt_sgemm calls. */
+int ldt_norm_points(const float* xyz, int32_t B, int32_t n, float* out, void* stream);
+int ldt_mixture_seed(const float* eps, const float* sig, const float* mu, const float* logits, int32_t n_mix, int32_t D, int64_t rows,
+                     float* out, void* stream);
 int ldt_knn(const float* xyz, const float* centers, int32_t B, int32_t n, int32_t S, int32_t k,
             int32_t* idx_out, float* dist_out, void* stream);
 int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx,

@@ -16,14 +16,21 @@ from .layers import ActNorm, FinalLayer, LabelEmbedding, MLP, ResidualBlock, _Ho
 
 # ----------------------------------------------------------------------------- parameter holders
 class InitialSet(_Holder):
-    """model/Compressor/layers.py:12-25 with max_outputs set: a learned (max_outputs, dim) query set."""
+    """model/Compressor/layers.py:12-25: a learned (max_outputs, dim) query set, or — max_outputs None — the parameters of a
+    mixture of n_mixtures Gaussians the seed rows are drawn from (same parameter names, shapes and construction order)."""
 
-    def __init__(self, dim_seed, max_outputs):
+    def __init__(self, dim_seed, max_outputs, n_mixtures=4):
         super().__init__()
-        if max_outputs is None:
-            raise NotImplementedError("mixture-of-Gaussians InitialSet (max_outputs=None) is not on the shipped path")
         self.dim_seed, self.max_outputs = dim_seed, max_outputs
-        self.prior = nn.Parameter(torch.rand((max_outputs, dim_seed), requires_grad=True))
+        if max_outputs is None:
+            import math
+            self.n_mixtures = n_mixtures
+            self.logits = nn.Parameter(torch.ones(n_mixtures, ))
+            self.mu = nn.Parameter(torch.randn(n_mixtures, dim_seed))
+            self.sig = nn.Parameter(torch.randn(n_mixtures, dim_seed).abs() / math.sqrt(n_mixtures))
+            self.output = nn.Sequential(nn.Linear(dim_seed, dim_seed), nn.SiLU(), nn.Linear(dim_seed, dim_seed))
+        else:
+            self.prior = nn.Parameter(torch.rand((max_outputs, dim_seed), requires_grad=True))
 
 
 class ConvBNReLU1D(_Holder):
@@ -155,10 +162,10 @@ class Compressor(nn.Module):
         self.norm_input = cfg.norm_input
         self.pre_group = cfg.pre_group
         self.class_condition = cfg.class_condition
-        if cfg.norm_input or cfg.pre_group or cfg.class_condition or cfg.pos_embedding == "mlp" or not cfg.ActNorm \
+        if cfg.class_condition or cfg.pos_embedding == "mlp" or not cfg.ActNorm \
                 or cfg.decoder_act is not None or cfg.encoder_dropout_p or cfg.decoder_dropout_p or not cfg.AdaLN:
             raise NotImplementedError("Compressor option outside the shipped configuration "
-                                      "(norm_input/pre_group/class_condition/pos_embedding=mlp/ActNorm off/decoder_act/dropout)")
+                                      "(class_condition/pos_embedding=mlp/ActNorm off/decoder_act/dropout)")
         self.input = nn.Conv1d(self.input_dim, self.hidden_dim, 1)
         self.ActNorm = cfg.ActNorm
         self.conv_in = ActNorm(self.hidden_dim, self.z_scales, feature_type=cfg.ActNorm)
@@ -176,6 +183,8 @@ class Compressor(nn.Module):
                                              c_dim=self.label_dim))
         self.output = nn.Conv1d(self.hidden_dim, 3, 1)
         self.init_set = InitialSet(self.hidden_dim, self.max_outputs)
+        if cfg.pre_group:                                               # Network.py:160-161 (created last, as upstream)
+            self.pre_grouper = LocalGrouper(self.hidden_dim, True, normalize=cfg.cluster_norm)
         self._pack, self._pack_key = None, None
         self.decode_chunk = 128          # samples per decode pass (activations ~7 MB/sample at 2048 points)
         # True: consume the CPU generator exactly as the reference does (B randperms per InitialSet call even when all rows
@@ -188,10 +197,19 @@ class Compressor(nn.Module):
         """InitialSet's row subset (Compressor/ops.py:6-14): B CPU `randperm(max_outputs) < num_points` masks, or None when
         every row is kept.  The reference draws the B permutations even then (quirk Q9) — 10 us each, which is half of a
         1024-cloud decode on this path — so that burn is only reproduced under `reference_rng`."""
-        if num_points == self.max_outputs and not self.reference_rng:
+        if self.max_outputs is None or (num_points == self.max_outputs and not self.reference_rng):
             return None
         presence = [torch.randperm(self.max_outputs) < num_points for _ in range(B)]
         return torch.stack(presence, 0) if num_points != self.max_outputs else None
+
+    def _draw_seed_eps(self, B, num_points):
+        """The N(0,1) draws of a mixture InitialSet (Compressor/layers.py:38): on the CPU generator like upstream under
+        `reference_rng`, else from the device Philox stream keyed by one CPU draw (4 MB per cloud at 2048 points)."""
+        shape = [B, num_points, self.init_set.n_mixtures, self.hidden_dim]
+        if self.reference_rng:
+            return torch.randn(shape).to(self._device())
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return ops.philox_normal(tuple(shape), self._device(), seed, step=1 << 20)
 
     def init(self):
         """Network.py:163-165 — marks ActNorm initialised (call after loading a checkpoint)."""
@@ -219,8 +237,15 @@ class Compressor(nn.Module):
                 P["enc"].append({"atts": [pack_block(a) for a in e.atts], "out": pack_final(e.conv_out)})
             P["w_out"], P["b_out"] = f32(conv_w(self.output)), f32(self.output.bias)
             P["w_input"], P["b_input"] = f32(conv_w(self.input)), f32(self.input.bias)
-            P["prior"] = f32(self.init_set.prior)
+            if self.max_outputs is None:
+                i = self.init_set
+                P["mix"] = {"logits": f32(i.logits), "mu": f32(i.mu), "sig": f32(i.sig), "w1": f32(i.output[0].weight), "b1": f32(i.output[0].bias),
+                            "w2": f32(i.output[2].weight), "b2": f32(i.output[2].bias)}
+            else:
+                P["prior"] = f32(self.init_set.prior)
             P["group"] = self.group.pack()
+            if self.pre_group:
+                P["pre_group"] = self.pre_grouper.pack()
             # MiniPointnet (Network.py:86-101), fp32
             pe = self.pos_embedding
             P["w_pe1"], P["b_pe1"] = _fold_bn(pe.conv1, pe.bn1)
@@ -232,8 +257,9 @@ class Compressor(nn.Module):
 
     # ------------------------------------------------------------------ decode (Network.py:251-268)
     @torch.no_grad()
-    def sample(self, shape, given_eps=None, keep_mask=None):
-        """Top-down generation: given_eps (B, tokens, n_layers*z_dim) -> points (B, N, 3)."""
+    def sample(self, shape, given_eps=None, keep_mask=None, seed_eps=None):
+        """Top-down generation: given_eps (B, tokens, n_layers*z_dim) -> points (B, N, 3).  seed_eps: with a mixture InitialSet
+        (max_outputs None), the (B, N, n_mixtures, hidden) draws of its seed rows (parity runs)."""
         B, num_points = shape[0], shape[1]
         num_points = self.outsize if num_points is None else num_points
         dev = self._device()
@@ -249,11 +275,22 @@ class Compressor(nn.Module):
         for b0 in range(0, B, self.decode_chunk):
             b1 = min(B, b0 + self.decode_chunk)
             km = None if keep_mask is None else keep_mask[b0:b1]
-            out[b0:b1] = self._decode_chunk(P, eps[b0:b1], num_points, km)
+            se = None if seed_eps is None else seed_eps[b0:b1]
+            out[b0:b1] = self._decode_chunk(P, eps[b0:b1], num_points, km, se)
         return self.postprocess(out)
 
-    def _initial_set(self, P, Bc, num_points, keep_mask):
-        """Compressor/layers.py:26-37: the learned prior rows, token-major fp32 [Bc*N, C]."""
+    def _initial_set(self, P, Bc, num_points, keep_mask, seed_eps=None):
+        """Compressor/layers.py:26-42: the learned prior rows, token-major fp32 [Bc*N, C]; or (max_outputs None) rows drawn from
+        the learned mixture — `seed_eps` (Bc, N, n_mixtures, C) replaces the N(0,1) draw of :38 — through the `output` MLP."""
+        if self.max_outputs is None:
+            M = P["mix"]
+            dev = M["mu"].device
+            if seed_eps is None:
+                seed_eps = self._draw_seed_eps(Bc, num_points)
+            e = seed_eps.to(dev, torch.float32).contiguous().view(Bc * num_points, self.init_set.n_mixtures, self.hidden_dim)
+            x = ops.mixture_seed(e, M["sig"], M["mu"], M["logits"])
+            h = ops.sgemm(x, M["w1"], M["b1"], act_out=ACT_SILU)
+            return ops.sgemm(h, M["w2"], M["b2"])
         prior = P["prior"]
         if keep_mask is None:
             return prior.unsqueeze(0).expand(Bc, -1, -1).reshape(Bc * num_points, -1).contiguous()
@@ -265,9 +302,9 @@ class Compressor(nn.Module):
         zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
         return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T)
 
-    def _decode_chunk(self, P, eps, N, keep_mask):
+    def _decode_chunk(self, P, eps, N, keep_mask, seed_eps=None):
         Bc, T, _ = eps.shape
-        o = self._initial_set(P, Bc, N, keep_mask)
+        o = self._initial_set(P, Bc, N, keep_mask, seed_eps)
         e2 = eps.view(Bc * T, -1)
         for j in range(self.n_layers):                                             # reversed(self.decoder), :263
             Pd = P["dec"][self.n_layers - 1 - j]
@@ -289,7 +326,7 @@ class Compressor(nn.Module):
 
     # ------------------------------------------------------------------ encode (Network.py:188-249)
     @torch.no_grad()
-    def forward(self, x, num_points=None, label=None, *, post_noise=None, want_stats=False):
+    def forward(self, x, num_points=None, label=None, *, post_noise=None, want_stats=False, seed_eps=None):
         """Bidirectional inference: x (B, N, 3) -> dict with 'all_eps' (B, tokens, n_layers*z_dim) and the
         reconstruction 'set' (B, N, 3).  `post_noise`: optional list of n_layers tensors (B, tokens, z_dim) replacing
         the N(0,1) draws of `sample(mu, logvar)` (Network.py:26-29).  Training-only entries of the reference dict
@@ -304,6 +341,8 @@ class Compressor(nn.Module):
         npts = self.outsize if num_points is None else num_points
         # reference order on the CPU generator: B randperms (InitialSet, :215) then one randn per level (:220)
         keep_mask = self._presence(B, npts)
+        if self.max_outputs is None and seed_eps is None:                 # (the mixture's seed rows are drawn first, :215 before :220)
+            seed_eps = self._draw_seed_eps(B, npts)
         if post_noise is None:
             if self.reference_rng:
                 post_noise = [torch.randn((B, z, T)).transpose(1, 2) for _ in range(L)]
@@ -312,10 +351,16 @@ class Compressor(nn.Module):
                 post_noise = [ops.philox_normal((B, T, z), dev, seed, step=j) for j in range(L)]
         P = self.packed()
         pts = x.to(dev, torch.float32).contiguous()
-        k = N // T * 2                                                              # Network.py:195
+        if self.norm_input:
+            pts = ops.norm_points(pts)                                              # norm_pts (:170-174, :189-190)
         # ---- bottom_up: input conv, FPS + kNN grouping, PreExtraction, pos embedding, ActNorm, encoder stages
         feat = ops.sgemm(pts.view(B * N, 3), P["w_input"], P["b_input"])            # Conv1d 3 -> D  (:192)
-        centers, tok, fps_idx, knn_idx = run_grouper(P["group"], pts, feat.view(B, N, D), T, k)
+        n_cur = N
+        if self.pre_group:                                                          # :193-194: 256 groups of 32 neighbours first
+            pts, feat, _, _ = run_grouper(P["pre_group"], pts, feat.view(B, N, D), 256, 32)
+            n_cur = 256
+        k = n_cur // T * 2                                                          # :195
+        centers, tok, fps_idx, knn_idx = run_grouper(P["group"], pts, feat.view(B, n_cur, D), T, k)
         tok_pre = tok.clone() if want_stats else None
         c1 = ops.sgemm(centers.view(B * T, 3), P["w_pe1"], P["b_pe1"], act_out=ACT_RELU)
         c2 = ops.sgemm(c1, P["w_pe2"], P["b_pe2"], act_out=ACT_RELU)
@@ -327,7 +372,7 @@ class Compressor(nn.Module):
                 residual_block(Pa, tok, B, T, y_bf16=ops.cast_pad_bf16(tok, ops.pad64(D)), Nk=T, c=pos)
             enc_out.append(final_layer(Pe["out"], tok, B, T, pos))
         # ---- top_down: posterior per level + decoder block
-        o = self._initial_set(P, B, npts, keep_mask)
+        o = self._initial_set(P, B, npts, keep_mask, seed_eps)
         all_eps = torch.empty((B * T, L * z), dtype=torch.float32, device=dev)
         stats = []
         for j in range(L):

@@ -150,6 +150,15 @@ extern "C" int ldt_group_normalize(const float* feat, const float* xyz, const in
     return ldt_group_launch(feat, xyz, fps_idx, knn_idx, alpha, beta, stats, B, n, S, k, D, BFM(U), ldu, center_mode, group_mean,
                             ST(stream));
 }
+extern "C" int ldt_norm_points(const float* xyz, int32_t B, int32_t n, float* out, void* stream) {
+    LDT_REQUIRE(xyz && out, LDT_EARG, "norm_points: null pointer");
+    return ldt_norm_points_launch(xyz, B, n, out, ST(stream));
+}
+extern "C" int ldt_mixture_seed(const float* eps, const float* sig, const float* mu, const float* logits, int32_t n_mix, int32_t D, int64_t rows,
+                                float* out, void* stream) {
+    LDT_REQUIRE(eps && sig && mu && logits && out, LDT_EARG, "mixture_seed: null pointer");
+    return ldt_mixture_seed_launch(eps, sig, mu, logits, n_mix, D, rows, out, ST(stream));
+}
 extern "C" int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream) {
     LDT_REQUIRE(src && idx && out, LDT_EARG, "gather_rows: null pointer");
     return ldt_gather_rows_launch(src, idx, B, n, S, C, out, ST(stream));

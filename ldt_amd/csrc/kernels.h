@@ -87,6 +87,8 @@ int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, 
 int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
                      const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu,
                      int center_mode, float* gmean, hipStream_t s);
+int ldt_norm_points_launch(const float* xyz, int B, int n, float* out, hipStream_t s);
+int ldt_mixture_seed_launch(const float* eps, const float* sig, const float* mu, const float* logits, int n_mix, int D, long rows, float* out, hipStream_t s);
 int ldt_gather_rows_launch(const float* src, const int* idx, int B, int n, int S, int C, float* out, hipStream_t s);
 int ldt_maxpool_launch(const void* in, int in_bf16, long ld, long G, int n, int C, float* out, hipStream_t s);
 int ldt_actnorm_launch(float* x, const float* shift, const float* log_scale, long B, long per_sample, hipStream_t s);

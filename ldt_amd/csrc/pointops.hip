@@ -445,3 +445,67 @@ int ldt_chamfer_launch(const float* a, const float* b, int B, int na, int nb, fl
     hipLaunchKernelGGL(chamfer_min_kernel, dim3((na + 255) / 256, B), dim3(256), 0, s, a, b, na, nb, dr);
     return ldt_check_launch("chamfer_dr");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Compressor.norm_pts (Network.py:170-174, cfg.norm_input): per cloud and coordinate, (p - mean) / std with the unbiased
+// standard deviation over the n points.  One 256-thread workgroup per cloud; sums in fp64 (n is a few thousand).
+__global__ __launch_bounds__(256) void norm_points_kernel(const float* __restrict__ xyz, int n, float* __restrict__ out) {
+    const float* p = xyz + (long)blockIdx.x * n * 3;
+    float* o = out + (long)blockIdx.x * n * 3;
+    double s[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const double v = p[3 * i + c]; s[c] += v; q[c] += v * v; }
+    __shared__ double red[4][6];
+    __shared__ float mean_s[3], inv_s[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { s[c] += __shfl_xor(s[c], o2, 64); q[c] += __shfl_xor(q[c], o2, 64); }
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { red[threadIdx.x >> 6][c] = s[c]; red[threadIdx.x >> 6][3 + c] = q[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const double ss = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        const double qq = (red[0][3 + c] + red[1][3 + c]) + (red[2][3 + c] + red[3][3 + c]);
+        const double mean = ss / n;
+        const double var = (qq - n * mean * mean) / (n - 1.0);
+        mean_s[c] = (float)mean;
+        inv_s[c] = (float)(1.0 / sqrt(var > 0.0 ? var : 0.0));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * n; i += 256) { const int c = i % 3; o[i] = (p[i] - mean_s[c]) * inv_s[c]; }
+}
+int ldt_norm_points_launch(const float* xyz, int B, int n, float* out, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 1, LDT_ESHAPE, "norm_points: B=%d n=%d", B, n);
+    hipLaunchKernelGGL(norm_points_kernel, dim3(B), dim3(256), 0, s, xyz, n, out);
+    return ldt_check_launch("norm_points");
+}
+
+// InitialSet with max_outputs = None (Compressor/layers.py:17-24,38-42): seed rows drawn from a learned mixture,
+//   x[r, d] = sum_m (eps[r, m, d] * sig[m, d] + mu[m, d]) * softmax(logits)[m],   r over B*N rows, m < n_mix (<= 8);
+// the two Linear layers of `output` that follow are plain fp32 GEMMs.
+__global__ __launch_bounds__(256) void mixture_seed_kernel(const float* __restrict__ eps, const float* __restrict__ sig, const float* __restrict__ mu,
+                                                           const float* __restrict__ logits, int n_mix, int D, long rows, float* __restrict__ out) {
+    float w[8];
+    float mx = -INFINITY, den = 0.f;
+    for (int m = 0; m < n_mix; ++m) mx = fmaxf(mx, logits[m]);
+    for (int m = 0; m < n_mix; ++m) { w[m] = expf(logits[m] - mx); den += w[m]; }
+    for (int m = 0; m < n_mix; ++m) w[m] /= den;
+    const long total = rows * D;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / D; const int d = (int)(i % D);
+        float acc = 0.f;
+        for (int m = 0; m < n_mix; ++m) acc += (eps[(r * n_mix + m) * D + d] * sig[m * D + d] + mu[m * D + d]) * w[m];
+        out[i] = acc;
+    }
+}
+int ldt_mixture_seed_launch(const float* eps, const float* sig, const float* mu, const float* logits, int n_mix, int D, long rows, float* out, hipStream_t s) {
+    LDT_REQUIRE(n_mix >= 1 && n_mix <= 8 && D > 0 && rows > 0, LDT_ESHAPE, "mixture_seed: n_mix=%d (<= 8) D=%d rows=%ld", n_mix, D, rows);
+    long blocks = (rows * D + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mixture_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, eps, sig, mu, logits, n_mix, D, rows, out);
+    return ldt_check_launch("mixture_seed");
+}

@@ -194,6 +194,26 @@ def fps(xyz, m, skip_near_origin=None):
     return idx
 
 
+def norm_points(xyz):
+    """Compressor.norm_pts (Network.py:170-174): xyz fp32 [B,n,3] -> (xyz - mean) / std per cloud and coordinate."""
+    _need(xyz, torch.float32, "xyz")
+    xyz = xyz.contiguous()
+    out = torch.empty_like(xyz)
+    check(lib().ldt_norm_points(_p(xyz), xyz.shape[0], xyz.shape[1], _p(out), stream_ptr()), "ldt_norm_points")
+    return out
+
+
+def mixture_seed(eps, sig, mu, logits):
+    """InitialSet mixture rows (Compressor/layers.py:38-41): eps fp32 [rows, n_mix, D] -> [rows, D]."""
+    for t, nm in ((eps, "eps"), (sig, "sig"), (mu, "mu"), (logits, "logits")):
+        _need(t, torch.float32, nm)
+    rows, n_mix, D = eps.shape
+    out = torch.empty((rows, D), dtype=torch.float32, device=eps.device)
+    check(lib().ldt_mixture_seed(_p(eps.contiguous()), _p(sig.contiguous()), _p(mu.contiguous()), _p(logits.contiguous()), n_mix, D, rows,
+                                 _p(out), stream_ptr()), "ldt_mixture_seed")
+    return out
+
+
 def knn(xyz, centers, k, return_dist=False):
     """-> int32 [B,S,k] unordered nearest-neighbour sets (+ the [B,S,n] distances)."""
     _need(xyz, torch.float32, "xyz"); _need(centers, torch.float32, "centers")

@@ -353,10 +353,16 @@ def sample_pndm(sde_cfg, score_fn, x0, time_eps):
 # ----------------------------------------------------------------------------- Compressor: decode
 
 
-def initial_set(sd, B, num_points=None, keep_mask=None):
-    """model/Compressor/layers.py:26-37 with max_outputs set: learned prior rows, token-major [B,N,D].
+def initial_set(sd, B, num_points=None, keep_mask=None, seed_eps=None):
+    """model/Compressor/layers.py:26-42.  max_outputs set: learned prior rows, token-major [B,N,D];
     keep_mask [B,max_outputs] bool selects rows (index order) when num_points < max_outputs;
-    with num_points == max_outputs every row is kept in order (quirk Q9)."""
+    with num_points == max_outputs every row is kept in order (quirk Q9).
+    max_outputs None (no 'init_set.prior' in the state_dict): seed_eps [B,N,n_mixtures,D] are the N(0,1) draws of :38,
+    x = sum_m (eps sig + mu) softmax(logits)_m, then the `output` MLP (:39-41)."""
+    if "init_set.prior" not in sd:
+        w = torch.softmax(sd["init_set.logits"], dim=0)
+        x = ((seed_eps * sd["init_set.sig"][None, None] + sd["init_set.mu"][None, None]) * w[None, None, :, None]).sum(2)
+        return linear(sd, "init_set.output.2", F.silu(linear(sd, "init_set.output.0", x)))
     prior = sd["init_set.prior"]
     if keep_mask is None:
         return prior[None].expand(B, -1, -1)
@@ -369,10 +375,10 @@ def decoder_block(sd, prefix, o, eps_j, num_heads):
     return residual_block(sd, prefix + ".att1", o, z, None, num_heads)
 
 
-def compressor_decode(sd, cfg, given_eps, keep_mask=None):
+def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
     """model/Compressor/Network.py:251-268 Compressor.sample: given_eps [B,T,n_layers*z_dim] -> [B,N,3]."""
     B = given_eps.shape[0]
-    o = initial_set(sd, B, keep_mask=keep_mask)
+    o = initial_set(sd, B, keep_mask=keep_mask, seed_eps=seed_eps)
     for j in range(cfg.n_layers):
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)                 # reversed(self.decoder), :263
         e_j = given_eps[:, :, cfg.z_dim * j: cfg.z_dim * (j + 1)]  # split along channels, :261-262
@@ -531,16 +537,21 @@ def act_norm(sd, prefix, x):
     return (x - sd[prefix + ".shift"]) * torch.exp(-sd[prefix + ".log_scale"])
 
 
-def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep_mask=None):
-    """model/Compressor/Network.py:188-249 Compressor.forward (norm_input False, pre_group False,
-    pos_embedding 'center', ActNorm True, class_condition False).
+def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep_mask=None, seed_eps=None):
+    """model/Compressor/Network.py:188-249 Compressor.forward (pos_embedding 'center', ActNorm True, class_condition False;
+    cfg.norm_input -> norm_pts :170-174, cfg.pre_group -> a first LocalGrouper of 256 groups x 32 neighbours :193-194).
 
     pts [B,N,3]; post_noise: list of n_layers tensors [B,T,z_dim] token-major — the N(0,1) draws
     of `sample(mu, logvar)` (:26-29) in consumption order.  Returns dict with 'all_eps' [B,T,n*z],
     'set' [B,N,3], plus intermediates for parity tests."""
     B, N, _ = pts.shape
     T = cfg.z_scales
+    if getattr(cfg, "norm_input", False):                                       # :189-190
+        pts = (pts - pts.mean(dim=1, keepdim=True)) / pts.std(dim=1, keepdim=True)
     feat = linear(sd, "input", pts)                                             # :192
+    if getattr(cfg, "pre_group", False):                                        # :193-194
+        pts, feat, _, _ = local_grouper(sd, "pre_grouper", pts, feat, 256, 32)
+        N = 256
     centers, x, fps_idx, knn_idx = local_grouper(sd, "group", pts, feat, T, N // T * 2, fps_idx, knn_idx)  # :195
     pos = mini_pointnet(sd, "pos_embedding", centers)                           # :196
     x = act_norm(sd, "conv_in", x)                                              # :200-201
@@ -549,7 +560,7 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
         for j in range(cfg.encoder_layers):
             x = residual_block(sd, "encoder.%d.atts.%d" % (i, j), x, x, pos, cfg.num_heads)   # y = raw x (Q2)
         enc_out.append(final_layer(sd, "encoder.%d.conv_out" % i, x, pos))
-    o = initial_set(sd, B, keep_mask=keep_mask)                                 # :215
+    o = initial_set(sd, B, keep_mask=keep_mask, seed_eps=seed_eps)              # :215
     all_eps, mus, logvars = [], [], []
     for j in range(cfg.n_layers):                                               # :217-225
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)

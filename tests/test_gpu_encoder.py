@@ -208,3 +208,34 @@ def test_compressor_rng_modes(tiny_cfg):
     s0 = torch.get_rng_state()
     comp.sample((B, 64), given_eps=e1)                                          # no idle randperms in the default mode
     assert torch.equal(torch.get_rng_state(), s0)
+
+
+def test_compressor_options_golden(tiny_cfg):
+    """norm_input + pre_group and the mixture InitialSet (max_outputs None) vs outputs captured from the reference."""
+    import copy
+    import ldt_amd
+    from conftest import load_golden, rel_mse
+    a, sds = load_golden("compressor_options")
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.compressor.n_layers, cfg.compressor.encoder_layers = 2, 1
+    ca = copy.deepcopy(cfg.compressor); ca.norm_input, ca.pre_group = True, True
+    ca.max_outputs = ca.outsize = 96
+    comp = ldt_amd.Compressor(ca)
+    comp.load_state_dict(sds["a"], strict=True)                    # incl. pre_grouper.*: same names, same order as upstream
+    comp = comp.cuda(); comp.init()
+    r = comp(a["a_pts"].cuda(), post_noise=list(a["a_post_noise"]))
+    assert rel_mse(r["all_eps"].cpu(), a["a_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["a_set"]) < 1e-3
+    cb = copy.deepcopy(cfg.compressor); cb.max_outputs = None
+    comp = ldt_amd.Compressor(cb)
+    comp.load_state_dict(sds["b"], strict=True)
+    comp = comp.cuda(); comp.init()
+    dec = comp.sample((2, 48), given_eps=a["b_given_eps"].cuda(), seed_eps=a["b_seed_eps"])
+    assert dec.shape == a["b_points"].shape and rel_mse(dec.cpu(), a["b_points"]) < 1e-4
+    r = comp(a["b_pts"].cuda(), post_noise=list(a["b_post_noise"]), seed_eps=a["b_fwd_seed_eps"])
+    assert rel_mse(r["all_eps"].cpu(), a["b_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["b_set"]) < 1e-3
+    comp.reference_rng = True                                       # the seed rows from a seeded CPU generator, like upstream
+    torch.manual_seed(79)
+    assert torch.equal(comp.sample((2, 48), given_eps=a["b_given_eps"].cuda()), dec)
+    comp.reference_rng = False
+    d1 = comp.sample((2, 48), given_eps=a["b_given_eps"].cuda())    # device Philox seed rows: finite, different draw
+    assert bool(torch.isfinite(d1).all()) and not torch.equal(d1, dec)

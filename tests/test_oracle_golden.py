@@ -191,6 +191,23 @@ def test_decoder_keep_mask(tiny_cfg):
     assert torch.equal(perms, a["perms"])
 
 
+def test_compressor_options(tiny_cfg):
+    """Options no shipped YAML uses, vs the reference: norm_input + pre_group (Network.py:170-174,188-195) and the
+    mixture-of-Gaussians InitialSet (max_outputs None, Compressor/layers.py:17-24,38-42)."""
+    import copy
+    a, sds = load_golden("compressor_options")
+    cc = copy.deepcopy(tiny_cfg.compressor)
+    cc.n_layers, cc.encoder_layers = 2, 1
+    ca = copy.deepcopy(cc); ca.norm_input, ca.pre_group = True, True
+    r = O.compressor_encode(sds["a"], ca, a["a_pts"], list(a["a_post_noise"]))
+    assert rel_mse(r["all_eps"], a["a_all_eps"]) < 1e-9 and rel_mse(r["set"], a["a_set"]) < 1e-9
+    assert abs(float(r["max"]) - float(a["a_max"])) < 1e-4 * abs(float(a["a_max"]))
+    dec = O.compressor_decode(sds["b"], cc, a["b_given_eps"], seed_eps=a["b_seed_eps"])
+    assert dec.shape == a["b_points"].shape and rel_mse(dec, a["b_points"]) < TOL
+    r = O.compressor_encode(sds["b"], cc, a["b_pts"], list(a["b_post_noise"]), seed_eps=a["b_fwd_seed_eps"])
+    assert rel_mse(r["all_eps"], a["b_all_eps"]) < 1e-9 and rel_mse(r["set"], a["b_set"]) < 1e-9
+
+
 def test_encoder(tiny_cfg):
     a, _ = load_golden("compressor_fwd_tiny")
     sd = load_golden("trainer_sample_tiny")[1]["c"]
