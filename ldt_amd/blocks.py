@@ -53,23 +53,25 @@ def pack_block(blk):
     return P
 
 
-def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
+def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False):
     """x fp32 [B*Nq, C] updated IN PLACE (and returned) when dim_out == dim_in; a NEW [B*Nq, dim_out] tensor is returned
     for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
-    c: fp32 [B, dim_c] condition (AdaLN) or None (affine LayerNorm block)."""
+    c: fp32 [B, dim_c] condition (AdaLN) — or [B*Nq, dim_c] with per_token=True (layers.py:210: a (B, dim_c, N) condition
+    modulates every token with its own row; the Compressor's `pos_embedding: mlp`) — or None (plain LayerNorm block)."""
     C, Co, H = P["C"], P["Co"], P["H"]
+    rps = 1 if per_token else Nq                                                    # rows that share one modulation row
     ln_kw = {}
     if c is not None and C == Co:
         mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                  # [B, 6C]  layers.py:214
         sh1, sc1, g1, sh2, sc2, g2 = (mod[:, i * C:(i + 1) * C] for i in range(6))
         s1 = s2 = 6 * C
-        ln_kw = dict(shift=sh1, scale=sc1, mod_sample_stride=s1, rows_per_sample=Nq)
+        ln_kw = dict(shift=sh1, scale=sc1, mod_sample_stride=s1, rows_per_sample=rps)
     elif c is not None:                                                             # layers.py:216-217
         m1 = ops.sgemm(c, P["wada1"], P["bada1"], act_in=ACT_SILU)                 # [B, 2C]   shift_msa | scale_msa
         mod = ops.sgemm(c, P["wada2"], P["bada2"], act_in=ACT_SILU)                # [B, 4Co]  gate_msa | shift_mlp | scale_mlp | gate_mlp
         g1, sh2, sc2, g2 = (mod[:, i * Co:(i + 1) * Co] for i in range(4))
         s2 = 4 * Co
-        ln_kw = dict(shift=m1[:, :C], scale=m1[:, C:], mod_sample_stride=2 * C, rows_per_sample=Nq)
+        ln_kw = dict(shift=m1[:, :C], scale=m1[:, C:], mod_sample_stride=2 * C, rows_per_sample=rps)
     else:
         g1 = g2 = None
         s2 = 0
@@ -98,7 +100,7 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
     if C != Co:                                                                     # shortcut(x): Conv1d dim_in -> dim_out
         from ._lib import EPI_F32
         x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)
-    if FUSED_ATTN and Co // H == 32 and H in (2, 4) and Nq % H == 0 and P["wo"].shape == (Co, Co):
+    if FUSED_ATTN and Co // H == 32 and H in (2, 4) and Nq % H == 0 and P["wo"].shape == (Co, Co) and not (per_token and g1 is not None):
         # attention + out-projection + gated residual in ONE kernel (csrc/attention.hip, OPROJ): the [B,H,Nq,Dh]
         # result never goes to HBM — the Compressor's d = 128 blocks
         ops.attention_oproj_resid_(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, 32, P["wo"], P["bo"], x, gate=g1,
@@ -106,22 +108,22 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None):
     else:
         a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)     # [B,H,Nq,Dh] == (B*Nq, Co) raw view
         ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
-                      gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=Nq)
+                      gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=rps)
     if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0:
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
         if c is not None:
             ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], shift=sh2, scale=sc2, gate=g2,
-                              mod_sample_stride=s2, rows_per_sample=Nq)
+                              mod_sample_stride=s2, rows_per_sample=rps)
         else:
             ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1])
         return x
     if c is not None:
-        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=Nq)
+        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
     else:
         h2 = ops.layernorm_modulate(x, w=P["n2"][0], b=P["n2"][1])
     u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
     ops.gemm_bf16(u, P["wdn"], P["bdn"], EPI_RESID_F32, out=x, resid=x, gate=g2,
-                  gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=Nq)
+                  gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=rps)
     return x
 
 
@@ -132,10 +134,10 @@ def pack_final(fl):
             "wada": lin.weight.detach().float().contiguous(), "bada": lin.bias.detach().float().contiguous()}
 
 
-def final_layer(P, x, B, N, c, out_dtype=torch.float32):
-    """FinalLayer with condition (layers.py:240-246): Conv(mod(LN(x)))."""
+def final_layer(P, x, B, N, c, out_dtype=torch.float32, per_token=False):
+    """FinalLayer with condition (layers.py:240-246): Conv(mod(LN(x))); c [B, dim_c], or [B*N, dim_c] with per_token."""
     from ._lib import EPI_F32
     C = P["C"]
     mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                      # [B, 2C] shift | scale
-    h = ops.layernorm_modulate(x, shift=mod[:, :C], scale=mod[:, C:], mod_sample_stride=2 * C, rows_per_sample=N)
+    h = ops.layernorm_modulate(x, shift=mod[:, :C], scale=mod[:, C:], mod_sample_stride=2 * C, rows_per_sample=1 if per_token else N)
     return ops.gemm_bf16(h, P["w"], P["b"], EPI_F32 if out_dtype == torch.float32 else EPI_BF16, n=P["n_out"])

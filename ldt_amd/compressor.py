@@ -120,8 +120,6 @@ class Encoder(_Holder):
 class DecoderBlock(_Holder):
     def __init__(self, dim_in, dim_z, num_heads, norm, mlp_ratio=4.0, min_sigma=-30., act=None, c_dim=None):
         super().__init__()
-        if c_dim is not None:
-            raise NotImplementedError("class-conditional decoder blocks are not on the shipped path")
         self.min_sigma = min_sigma
         self.att = ResidualBlock(dim_in, dim_in, c_dim, num_heads, norm, mlp_ratio, act=act)
         self.prior = nn.Sequential(nn.SiLU(), nn.Conv1d(dim_in, 2 * dim_z, 1))
@@ -162,10 +160,11 @@ class Compressor(nn.Module):
         self.norm_input = cfg.norm_input
         self.pre_group = cfg.pre_group
         self.class_condition = cfg.class_condition
-        if cfg.class_condition or cfg.pos_embedding == "mlp" or not cfg.ActNorm \
-                or cfg.decoder_act is not None or cfg.encoder_dropout_p or cfg.decoder_dropout_p or not cfg.AdaLN:
-            raise NotImplementedError("Compressor option outside the shipped configuration "
-                                      "(class_condition/pos_embedding=mlp/ActNorm off/decoder_act/dropout)")
+        if not cfg.ActNorm or cfg.decoder_act is not None or cfg.encoder_dropout_p or cfg.decoder_dropout_p or not cfg.AdaLN:
+            raise NotImplementedError("Compressor option outside the built configurations (ActNorm off / decoder_act / dropout / AdaLN off)")
+        if cfg.class_condition and cfg.pos_embedding == "mlp":
+            raise NotImplementedError("class_condition with pos_embedding=mlp: the reference adds a (B, p_dim) label embedding to a "
+                                      "(B, p_dim, tokens) position condition (Network.py:197-198), which does not broadcast")
         self.input = nn.Conv1d(self.input_dim, self.hidden_dim, 1)
         self.ActNorm = cfg.ActNorm
         self.conv_in = ActNorm(self.hidden_dim, self.z_scales, feature_type=cfg.ActNorm)
@@ -173,8 +172,15 @@ class Compressor(nn.Module):
         self.decoder = nn.ModuleList()
         self.upsample = nn.ModuleList()
         self.group = LocalGrouper(self.hidden_dim, True, normalize=cfg.cluster_norm)
-        self.pos_embedding = MiniPointnet(3, self.p_dim)
-        self.label_dim = None
+        if cfg.pos_embedding == "mlp":                                  # Network.py:133-136: a per-token position condition
+            self.pos_embedding = MLP(dim_in=3, dim_hidden=self.p_dim, dim_out=self.p_dim, n_hidden=1)
+        else:
+            self.pos_embedding = MiniPointnet(3, self.p_dim)
+        if cfg.class_condition:                                         # :137-142
+            self.LabelEmbedding = LabelEmbedding(cfg.num_categorys, self.p_dim, self.p_dim)
+            self.label_dim = self.p_dim
+        else:
+            self.label_dim = None
         for i in range(self.n_layers):
             self.encoder.append(Encoder(self.hidden_dim, self.p_dim, self.num_heads, norm=self.norm,
                                         num_layers=self.encoder_layers, mlp_ratio=self.mlp_ratio))
@@ -246,11 +252,18 @@ class Compressor(nn.Module):
             P["group"] = self.group.pack()
             if self.pre_group:
                 P["pre_group"] = self.pre_grouper.pack()
-            # MiniPointnet (Network.py:86-101), fp32
             pe = self.pos_embedding
-            P["w_pe1"], P["b_pe1"] = _fold_bn(pe.conv1, pe.bn1)
-            P["w_pe2"], P["b_pe2"] = _fold_bn(pe.conv2, pe.bn2)
-            P["w_pefc"], P["b_pefc"] = f32(pe.fc.weight), f32(pe.fc.bias)
+            if isinstance(pe, MLP):                                      # pos_embedding: mlp — Conv1d 3 -> p, GELU, Conv1d p -> p per centre
+                P["w_pm1"], P["b_pm1"] = f32(conv_w(pe.fc[0][0])), f32(pe.fc[0][0].bias)
+                P["w_pm2"], P["b_pm2"] = f32(conv_w(pe.out)), f32(pe.out.bias)
+            else:                                                        # MiniPointnet (Network.py:86-101), fp32
+                P["w_pe1"], P["b_pe1"] = _fold_bn(pe.conv1, pe.bn1)
+                P["w_pe2"], P["b_pe2"] = _fold_bn(pe.conv2, pe.bn2)
+                P["w_pefc"], P["b_pefc"] = f32(pe.fc.weight), f32(pe.fc.bias)
+            if self.class_condition:
+                le = self.LabelEmbedding
+                P["label"] = {"emb": f32(le.label_emb.weight), "w1": f32(le.mlp[0].weight), "b1": f32(le.mlp[0].bias),
+                              "w2": f32(le.mlp[2].weight), "b2": f32(le.mlp[2].bias)}
             P["an_shift"], P["an_logs"] = f32(self.conv_in.shift.reshape(-1)), f32(self.conv_in.log_scale.reshape(-1))
         self._pack, self._pack_key = P, key
         return P
@@ -297,10 +310,11 @@ class Compressor(nn.Module):
         km = keep_mask.to(prior.device)
         return torch.stack([prior[km[b]] for b in range(Bc)], 0).reshape(Bc * num_points, -1).contiguous()
 
-    def _decoder_level(self, Pd, o, eps_j, Bc, N, T):
-        """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j))."""
+    def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None):
+        """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j), c); c = label embedding in a class-conditional
+        forward, None in `sample` (which never passes one, :263-264: the block then runs its plain-LayerNorm branch)."""
         zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
-        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T)
+        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c)
 
     def _decode_chunk(self, P, eps, N, keep_mask, seed_eps=None):
         Bc, T, _ = eps.shape
@@ -331,8 +345,6 @@ class Compressor(nn.Module):
         reconstruction 'set' (B, N, 3).  `post_noise`: optional list of n_layers tensors (B, tokens, z_dim) replacing
         the N(0,1) draws of `sample(mu, logvar)` (Network.py:26-29).  Training-only entries of the reference dict
         ('kls', 'all_logqz') are not produced; 'posteriors' holds token-major (mu, logvar) when want_stats."""
-        if label is not None:
-            raise NotImplementedError("class-conditional Compressor is not on the shipped path")
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("Compressor.forward: parameters on %s; the HIP path has no CPU fallback" % dev)
@@ -362,15 +374,26 @@ class Compressor(nn.Module):
         k = n_cur // T * 2                                                          # :195
         centers, tok, fps_idx, knn_idx = run_grouper(P["group"], pts, feat.view(B, n_cur, D), T, k)
         tok_pre = tok.clone() if want_stats else None
-        c1 = ops.sgemm(centers.view(B * T, 3), P["w_pe1"], P["b_pe1"], act_out=ACT_RELU)
-        c2 = ops.sgemm(c1, P["w_pe2"], P["b_pe2"], act_out=ACT_RELU)
-        pos = ops.sgemm(ops.maxpool(c2, B, T), P["w_pefc"], P["b_pefc"])            # [B, p_dim]
+        per_tok = "w_pm1" in P
+        if per_tok:                                                                 # pos_embedding: mlp (:133-134): one row per token
+            from ._lib import ACT_GELU
+            pos = ops.sgemm(ops.sgemm(centers.view(B * T, 3), P["w_pm1"], P["b_pm1"], act_out=ACT_GELU), P["w_pm2"], P["b_pm2"])
+        else:
+            c1 = ops.sgemm(centers.view(B * T, 3), P["w_pe1"], P["b_pe1"], act_out=ACT_RELU)
+            c2 = ops.sgemm(c1, P["w_pe2"], P["b_pe2"], act_out=ACT_RELU)
+            pos = ops.sgemm(ops.maxpool(c2, B, T), P["w_pefc"], P["b_pefc"])        # [B, p_dim]
+        l_emb = None
+        if label is not None and self.class_condition:                              # :240-241, :197-198 (ignored otherwise, as upstream)
+            PL = P["label"]
+            e = PL["emb"][label.to(dev).long()].contiguous()
+            l_emb = ops.sgemm(ops.sgemm(e, PL["w1"], PL["b1"], act_out=ACT_SILU), PL["w2"], PL["b2"])
+            pos = pos + l_emb
         ops.actnorm_(tok, P["an_shift"], P["an_logs"], B)
         enc_out = []
         for Pe in P["enc"]:                                                         # Network.py:203-205, 41-45
             for Pa in Pe["atts"]:
-                residual_block(Pa, tok, B, T, y_bf16=ops.cast_pad_bf16(tok, ops.pad64(D)), Nk=T, c=pos)
-            enc_out.append(final_layer(Pe["out"], tok, B, T, pos))
+                residual_block(Pa, tok, B, T, y_bf16=ops.cast_pad_bf16(tok, ops.pad64(D)), Nk=T, c=pos, per_token=per_tok)
+            enc_out.append(final_layer(Pe["out"], tok, B, T, pos, per_token=per_tok))
         # ---- top_down: posterior per level + decoder block
         o = self._initial_set(P, B, npts, keep_mask, seed_eps)
         all_eps = torch.empty((B * T, L * z), dtype=torch.float32, device=dev)
@@ -382,12 +405,12 @@ class Compressor(nn.Module):
                 y, nk = ops.cast_pad_bf16(xj, ops.pad64(D)), T                       # compute_posterior(x, None): att(x, x)
             else:
                 y, nk = ops.cast_pad_bf16(o, ops.pad64(D)), npts                    # att(x, o): K/V = 2048 decoded points
-            residual_block(Pd["att"], xj, B, T, y_bf16=y, Nk=nk)
+            residual_block(Pd["att"], xj, B, T, y_bf16=y, Nk=nk, c=l_emb)
             post = ops.sgemm(xj, Pd["w_prior"], Pd["b_prior"], act_in=ACT_SILU)      # SiLU -> Conv1d D -> 2z
             nz = post_noise[j].to(dev, torch.float32).contiguous().view(B * T, z)
             ej = all_eps[:, z * j: z * (j + 1)]
             stats.append(ops.reparam(post, nz, ej, self.min_sigma, 10., want_stats))
-            self._decoder_level(Pd, o, ej, B, npts, T)
+            self._decoder_level(Pd, o, ej, B, npts, T, c=l_emb)
         out = ops.sgemm(o, P["w_out"], P["b_out"]).view(B, npts, 3)
         res = {"set": self.postprocess(out), "all_eps": all_eps.view(B, T, L * z), "max": tok.max(),
                "posteriors": [(all_eps.view(B, T, L * z)[..., z * j: z * (j + 1)],) + tuple(

@@ -62,6 +62,37 @@ def main():
     out.update(b_pts=pts, b_fwd_seed_eps=rec.draws[0][1],
                b_post_noise=torch.stack([d.transpose(1, 2) for _, d in rec.draws[1:]], 0),
                b_all_eps=res["all_eps"], b_set=res["set"], **sd_np(comp.state_dict(), "b::"))
+    # ---- (c) pos_embedding: mlp (per-token position condition) --------------------------------------------------------
+    cfg = tiny_cfg()
+    cfg.compressor.n_layers, cfg.compressor.encoder_layers = 2, 1
+    cfg.compressor.pos_embedding = "mlp"
+    torch.manual_seed(7)
+    comp = Compressor(cfg.compressor).eval()
+    comp.init()
+    randomize_norm_stats(comp, g)
+    pts = torch.randn(2, 64, 3, generator=g)
+    torch.manual_seed(81)
+    with Recorder() as rec:
+        res = comp(pts)
+    out.update(c_pts=pts, c_post_noise=torch.stack([d.transpose(1, 2) for k, d in rec.draws if k == "randn"], 0),
+               c_all_eps=res["all_eps"], c_set=res["set"], **sd_np(comp.state_dict(), "c::"))
+    # ---- (d) class_condition: LabelEmbedding into the position condition and the decoder blocks -----------------------
+    cfg = tiny_cfg()
+    cfg.compressor.n_layers, cfg.compressor.encoder_layers = 2, 1
+    cfg.compressor.class_condition, cfg.compressor.num_categorys = True, 5
+    torch.manual_seed(8)
+    comp = Compressor(cfg.compressor).eval()
+    comp.init()
+    randomize_norm_stats(comp, g)
+    label = torch.tensor([3, 1])
+    torch.manual_seed(82)
+    with Recorder() as rec:
+        res = comp(pts, label=label)
+    geps = out["b_given_eps"]
+    torch.manual_seed(83)
+    dec = comp.sample((2, 64), given_eps=geps)                     # decode ignores labels (:251-268): plain-LayerNorm branch of AdaLN-built blocks
+    out.update(d_label=label, d_post_noise=torch.stack([d.transpose(1, 2) for k, d in rec.draws if k == "randn"], 0),
+               d_all_eps=res["all_eps"], d_set=res["set"], d_points=dec, **sd_np(comp.state_dict(), "d::"))
     save("compressor_options", **out)
 
 

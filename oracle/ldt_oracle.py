@@ -116,22 +116,24 @@ def residual_block(sd, prefix, x, y, c, num_heads):
         x = linear(sd, prefix + ".shortcut", x) + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
         x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
     elif c is not None:
-        m = linear(sd, prefix + ".adaLN.1", F.silu(c))[:, None, :]      # [B,1,6C]
+        m = linear(sd, prefix + ".adaLN.1", F.silu(c))                   # [B,6C], or [B,T,6C] for a per-token condition (:210)
+        m = m[:, None, :] if m.dim() == 2 else m
         sh1, sc1, g1, sh2, sc2, g2 = m.chunk(6, dim=-1)
         h = modulate(layer_norm(x), sh1, sc1)
         x = x + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
         x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
-    else:
-        h = layer_norm(x, sd[prefix + ".norm1.norm.weight"], sd[prefix + ".norm1.norm.bias"])
+    else:                                # (a block BUILT with a condition but called without one has no affine: :172-173)
+        h = layer_norm(x, sd.get(prefix + ".norm1.norm.weight"), sd.get(prefix + ".norm1.norm.bias"))
         x = x + attention(sd, prefix, h, h if y is None else y, num_heads)
-        h = layer_norm(x, sd[prefix + ".norm2.norm.weight"], sd[prefix + ".norm2.norm.bias"])
+        h = layer_norm(x, sd.get(prefix + ".norm2.norm.weight"), sd.get(prefix + ".norm2.norm.bias"))
         x = x + mlp(sd, prefix + ".mlp", h)
     return x
 
 
 def final_layer(sd, prefix, x, c):
     """model/layers.py:232-248: chunk order is (shift, scale)."""
-    m = linear(sd, prefix + ".adaLN.1", F.silu(c))[:, None, :]
+    m = linear(sd, prefix + ".adaLN.1", F.silu(c))
+    m = m[:, None, :] if m.dim() == 2 else m
     sh, sc = m.chunk(2, dim=-1)
     return linear(sd, prefix + ".ln", modulate(layer_norm(x), sh, sc))
 
@@ -369,10 +371,10 @@ def initial_set(sd, B, num_points=None, keep_mask=None, seed_eps=None):
     return torch.stack([prior[keep_mask[b]] for b in range(B)], 0)
 
 
-def decoder_block(sd, prefix, o, eps_j, num_heads):
-    """model/Compressor/Network.py:80-83: o <- att1(o, ln(eps_j)) (no-condition block, K/V raw)."""
+def decoder_block(sd, prefix, o, eps_j, num_heads, c=None):
+    """model/Compressor/Network.py:80-83: o <- att1(o, ln(eps_j), c) (K/V raw; c: label embedding under class_condition)."""
     z = linear(sd, prefix + ".ln", eps_j)
-    return residual_block(sd, prefix + ".att1", o, z, None, num_heads)
+    return residual_block(sd, prefix + ".att1", o, z, c, num_heads)
 
 
 def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
@@ -537,9 +539,11 @@ def act_norm(sd, prefix, x):
     return (x - sd[prefix + ".shift"]) * torch.exp(-sd[prefix + ".log_scale"])
 
 
-def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep_mask=None, seed_eps=None):
-    """model/Compressor/Network.py:188-249 Compressor.forward (pos_embedding 'center', ActNorm True, class_condition False;
-    cfg.norm_input -> norm_pts :170-174, cfg.pre_group -> a first LocalGrouper of 256 groups x 32 neighbours :193-194).
+def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep_mask=None, seed_eps=None, label=None):
+    """model/Compressor/Network.py:188-249 Compressor.forward (ActNorm True;
+    cfg.norm_input -> norm_pts :170-174, cfg.pre_group -> a first LocalGrouper of 256 groups x 32 neighbours :193-194,
+    cfg.pos_embedding 'mlp' -> a per-token position condition MLP(centres) :133-134, cfg.class_condition + label ->
+    LabelEmbedding added to the position condition and fed to the decoder blocks :137-142,197-198,218,225).
 
     pts [B,N,3]; post_noise: list of n_layers tensors [B,T,z_dim] token-major — the N(0,1) draws
     of `sample(mu, logvar)` (:26-29) in consumption order.  Returns dict with 'all_eps' [B,T,n*z],
@@ -553,7 +557,15 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
         pts, feat, _, _ = local_grouper(sd, "pre_grouper", pts, feat, 256, 32)
         N = 256
     centers, x, fps_idx, knn_idx = local_grouper(sd, "group", pts, feat, T, N // T * 2, fps_idx, knn_idx)  # :195
-    pos = mini_pointnet(sd, "pos_embedding", centers)                           # :196
+    if getattr(cfg, "pos_embedding", "center") == "mlp":                        # :133-134, :196  [B,T,p_dim]
+        pos = linear(sd, "pos_embedding.out", F.gelu(linear(sd, "pos_embedding.fc.0.0", centers)))
+    else:
+        pos = mini_pointnet(sd, "pos_embedding", centers)                       # :196  [B,p_dim]
+    l_emb = None
+    if label is not None and getattr(cfg, "class_condition", False):            # :240-241, layers.py:44-52
+        e = sd["LabelEmbedding.label_emb.weight"][label]
+        l_emb = linear(sd, "LabelEmbedding.mlp.2", F.silu(linear(sd, "LabelEmbedding.mlp.0", e)))
+        pos = pos + l_emb                                                       # :197-198
     x = act_norm(sd, "conv_in", x)                                              # :200-201
     enc_out = []
     for i in range(cfg.n_layers):                                               # :203-205
@@ -565,12 +577,12 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
     for j in range(cfg.n_layers):                                               # :217-225
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)
         xj = enc_out[-j - 1]
-        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, None, cfg.num_heads)   # :61-74
+        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, l_emb, cfg.num_heads)   # :61-74
         post = linear(sd, blk + ".prior.1", F.silu(p))                          # :56,:72
         mu = post[..., :cfg.z_dim]
         logvar = post[..., cfg.z_dim:].clamp(cfg.min_sigma, 10.)                # :76
         eps = mu + torch.exp(logvar / 2.) * post_noise[j]                       # :26-29
-        o = decoder_block(sd, blk, o, eps, cfg.num_heads)                       # :225
+        o = decoder_block(sd, blk, o, eps, cfg.num_heads, l_emb)                # :225
         all_eps.append(eps); mus.append(mu); logvars.append(logvar)
     out = linear(sd, "output", o)                                               # :231
     return {"set": out, "all_eps": torch.cat(all_eps, dim=-1), "mu": mus, "logvar": logvars,

@@ -233,6 +233,23 @@ def test_compressor_options_golden(tiny_cfg):
     assert dec.shape == a["b_points"].shape and rel_mse(dec.cpu(), a["b_points"]) < 1e-4
     r = comp(a["b_pts"].cuda(), post_noise=list(a["b_post_noise"]), seed_eps=a["b_fwd_seed_eps"])
     assert rel_mse(r["all_eps"].cpu(), a["b_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["b_set"]) < 1e-3
+    # pos_embedding: mlp — every token is modulated by its own AdaLN row (blocks.residual_block per_token)
+    cm = copy.deepcopy(cfg.compressor); cm.pos_embedding = "mlp"
+    cmod = ldt_amd.Compressor(cm)
+    cmod.load_state_dict(sds["c"], strict=True)
+    cmod = cmod.cuda(); cmod.init()
+    r = cmod(a["c_pts"].cuda(), post_noise=list(a["c_post_noise"]))
+    assert rel_mse(r["all_eps"].cpu(), a["c_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["c_set"]) < 1e-3
+    # class_condition: label embedding in the position condition and the (AdaLN) decoder blocks; decode ignores labels
+    cl = copy.deepcopy(cfg.compressor); cl.class_condition, cl.num_categorys = True, 5
+    cmod = ldt_amd.Compressor(cl)
+    cmod.load_state_dict(sds["d"], strict=True)
+    cmod = cmod.cuda(); cmod.init()
+    r = cmod(a["c_pts"].cuda(), label=a["d_label"].cuda(), post_noise=list(a["d_post_noise"]))
+    assert rel_mse(r["all_eps"].cpu(), a["d_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["d_set"]) < 1e-3
+    nolabel = cmod(a["c_pts"].cuda(), post_noise=list(a["d_post_noise"]))
+    assert rel_mse(nolabel["all_eps"].cpu(), a["d_all_eps"]) > 1e-3
+    assert rel_mse(cmod.sample((2, 64), given_eps=a["b_given_eps"].cuda()).cpu(), a["d_points"]) < 1e-4
     comp.reference_rng = True                                       # the seed rows from a seeded CPU generator, like upstream
     torch.manual_seed(79)
     assert torch.equal(comp.sample((2, 48), given_eps=a["b_given_eps"].cuda()), dec)

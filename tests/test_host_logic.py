@@ -148,8 +148,14 @@ def test_unsupported_options_raise(tiny_cfg):
     names = list(ldt_amd.Score(c.score).state_dict())
     assert "Transformer_Down.0.shortcut.weight" in names and "Transformer_Mid.adaLN.1.weight" in names
     assert not any(n.startswith("Transformer.") for n in names)
-    c = copy.deepcopy(tiny_cfg)
+    c = copy.deepcopy(tiny_cfg)                    # built since round 2: per-token position condition, class labels, mixture seeds
     c.compressor.pos_embedding = "mlp"
+    assert "pos_embedding.fc.0.0.weight" in ldt_amd.Compressor(c.compressor).state_dict()
+    c.compressor.class_condition, c.compressor.num_categorys = True, 5
+    with pytest.raises(NotImplementedError):       # (B, p) label + (B, p, tokens) position condition: does not broadcast upstream either
+        ldt_amd.Compressor(c.compressor)
+    c = copy.deepcopy(tiny_cfg)
+    c.compressor.decoder_act = "swish"
     with pytest.raises(NotImplementedError):
         ldt_amd.Compressor(c.compressor)
 

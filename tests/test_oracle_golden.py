@@ -206,6 +206,14 @@ def test_compressor_options(tiny_cfg):
     assert dec.shape == a["b_points"].shape and rel_mse(dec, a["b_points"]) < TOL
     r = O.compressor_encode(sds["b"], cc, a["b_pts"], list(a["b_post_noise"]), seed_eps=a["b_fwd_seed_eps"])
     assert rel_mse(r["all_eps"], a["b_all_eps"]) < 1e-9 and rel_mse(r["set"], a["b_set"]) < 1e-9
+    # pos_embedding: mlp (per-token position condition, Network.py:133-134) and class_condition (:137-142,197-198,218,225)
+    cm = copy.deepcopy(cc); cm.pos_embedding = "mlp"
+    r = O.compressor_encode(sds["c"], cm, a["c_pts"], list(a["c_post_noise"]))
+    assert rel_mse(r["all_eps"], a["c_all_eps"]) < 1e-9 and rel_mse(r["set"], a["c_set"]) < 1e-9
+    cl = copy.deepcopy(cc); cl.class_condition, cl.num_categorys = True, 5
+    r = O.compressor_encode(sds["d"], cl, a["c_pts"], list(a["d_post_noise"]), label=a["d_label"])
+    assert rel_mse(r["all_eps"], a["d_all_eps"]) < 1e-9 and rel_mse(r["set"], a["d_set"]) < 1e-9
+    assert rel_mse(O.compressor_decode(sds["d"], cl, a["b_given_eps"]), a["d_points"]) < TOL    # decode never sees a label
 
 
 def test_encoder(tiny_cfg):
