@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — imports the upstream Python reference on CPU.
 
 Runs ONLY in the build container where /root/reference exists (it never travels
-to the GPU box).  Used by `oracle/gen_golden.py` to capture golden vectors and by
-`tests/test_oracle_vs_reference.py` (auto-skipped when /root/reference is absent).
+to the GPU box).  Used by the `oracle/gen_*golden.py` scripts to capture golden vectors and by
+`tests/test_host_logic.py::test_default_init_draws_same_weights_as_reference` (auto-skipped when /root/reference is absent).
 
 The reference hard-codes `'cuda'` devices and imports packages that are not in
 this image; this module installs the minimum shims to run it on CPU:
