@@ -411,3 +411,33 @@ def test_fused_ln_linear(C, M, N, mode):
     assert rel_mse(got.float().cpu(), want) < 1e-4
     two = ops.gemm_bf16(ops.layernorm_modulate(x.cuda(), **{({"ln_w": "w", "ln_b": "b"}.get(k, k)): v for k, v in kw.items()}), wb, b.cuda())
     assert rel_mse(got.float().cpu(), two.float().cpu()) < 2e-5
+
+
+def test_resid_ring_epilogue_is_bit_identical_to_plain_loads():
+    """The residual GEMM of a one-tile-per-workgroup launch reads its fp32 residual rows through the idle operand ring
+    (LDS-DMA, counted waits); any non-zero debug knob switches that off without changing the arithmetic (bit 32 skips
+    nothing): x, x(1+scale) and the row statistics must agree bit for bit, producer (LN folding) and plain form."""
+    from ldt_amd import _lib
+    from ldt_amd._lib import EPI_RESID_F32
+    g = torch.Generator().manual_seed(12)
+    for M, K in ((4096, 1024), (16384, 4096)):
+        N = 1024                                              # M/256 * 4 <= 256 tiles: every workgroup has one tile
+        a = (torch.randn(M, K, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().to(torch.bfloat16)
+        b = torch.randn(N, generator=g).cuda(); gate = torch.randn(N, generator=g).cuda(); sc = (0.2 * torch.randn(N, generator=g)).cuda()
+        x0 = (torch.randn(M, N, generator=g) + 0.3).cuda()
+        outs = []
+        for bits in (0, 32):
+            _lib.lib().ldt_dbg_gemm_epi(bits)
+            x = x0.clone()
+            xs, st = ops.gemm_resid_lnstats(a, w, b, x, sc, gate=gate, rows_per_sample=256)
+            y = x0.clone()
+            ops.gemm_bf16(a, w, b, EPI_RESID_F32, out=y, resid=y, gate=gate, rows_per_sample=256)
+            torch.cuda.synchronize()
+            outs.append((x, xs, st, y))
+        _lib.lib().ldt_dbg_gemm_epi(-1)
+        for p, q in zip(*outs):
+            assert torch.equal(p, q)
+        assert torch.equal(outs[0][0], outs[0][3])            # producer's x == the plain residual GEMM's x
+        ref = x0.double().cpu() + gate.double().cpu() * (a.double().cpu() @ w.double().cpu().T + b.double().cpu())
+        assert rel_mse(outs[0][0].cpu(), ref) < 1e-9

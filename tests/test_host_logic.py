@@ -282,3 +282,24 @@ def test_graphconv_is_rejected_like_the_reference(tiny_cfg):
     tr = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor), "cpu")
     with pytest.raises(RuntimeError, match="graphconv"):
         tr.sample(2)
+
+
+def test_bench_traffic_provenance(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic is the PMC measurement committed under profiles/ only while the kernel sources are the
+    ones it was collected on; otherwise the value is withheld and the provenance says why."""
+    import json
+    import bench
+    sha = bench.csrc_sha()
+    assert len(sha) == 16 and sha == bench.csrc_sha()
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    entry = {"hbm_bytes_per_launch": 123, "source": "profiles/x.csv", "csrc_sha": sha, "note": "n"}
+    (root / "profiles" / "traffic.json").write_text(json.dumps({"k<1>": entry, "k<2>": dict(entry, csrc_sha="0" * 16)}))
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    monkeypatch.setattr(bench, "csrc_sha", lambda: sha)
+    v, prov = bench.measured_traffic("k<1>")
+    assert v == 123 and prov["status"] == "current" and prov["source"] == "profiles/x.csv"
+    v, prov = bench.measured_traffic("k<2>")
+    assert v is None and prov["status"].startswith("stale") and prov["collected_on_csrc_sha"] == "0" * 16
+    v, prov = bench.measured_traffic("k<3>")
+    assert v is None and "no measurement" in prov["status"]
