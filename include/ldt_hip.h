@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 9
+#define LDT_ABI_VERSION 10
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -195,11 +195,13 @@ int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na, int32_t n
  * In place on x fp32 [M][ldx]:  x += gate * (W_dn . GELU(W_up . h + b_up) + b_dn),  h = LN(x) * ln_w + ln_b  (affine,
  * no-condition blocks) or LN(x) * (1 + scale) + shift (AdaLN; shift/scale/gate are per-sample vectors, sample =
  * row / rows_per_sample, consecutive samples mod_sample_stride floats apart).  C in {64, 128}; w_up bf16 [4C][C],
- * w_dn bf16 [C][4C], both row-major and dense.  One pass over x instead of LayerNorm + two GEMMs. */
+ * w_dn bf16 [C][4C], both row-major and dense.  One pass over x instead of LayerNorm + two GEMMs.
+ * x_bf16 (or NULL): bf16 [M][ldxb] copy of the updated x, written in the same pass — the next DecoderBlock level reads the
+ * decoded set as its K/V source (Network.py:229 `att(x, o)`), which otherwise costs a separate cast pass over x. */
 int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
                      const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
                      int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
-                     const float* b_dn, void* stream);
+                     const float* b_dn, uint16_t* x_bf16, int64_t ldxb, void* stream);
 
 /* LayerNorm + linear for the same narrow blocks: out bf16 [M][ldo] = LN(x)[affine | modulated] . W^T + bias, W bf16 [N][C]
  * dense, N % 64 == 0, C in {64, 128} — fc_q (and fc_kv when the block attends to its own normalised input,

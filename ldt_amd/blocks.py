@@ -53,11 +53,13 @@ def pack_block(blk):
     return P
 
 
-def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False):
+def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None):
     """x fp32 [B*Nq, C] updated IN PLACE (and returned) when dim_out == dim_in; a NEW [B*Nq, dim_out] tensor is returned
     for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
     c: fp32 [B, dim_c] condition (AdaLN) — or [B*Nq, dim_c] with per_token=True (layers.py:210: a (B, dim_c, N) condition
-    modulates every token with its own row; the Compressor's `pos_embedding: mlp`) — or None (plain LayerNorm block)."""
+    modulates every token with its own row; the Compressor's `pos_embedding: mlp`) — or None (plain LayerNorm block).
+    x_bf16_out: optional bf16 [B*Nq, dim_out] buffer that receives a copy of the block's result (written by the fused MLP
+    kernel's own store pass, or by one cast on the unfused path)."""
     C, Co, H = P["C"], P["Co"], P["H"]
     rps = 1 if per_token else Nq                                                    # rows that share one modulation row
     ln_kw = {}
@@ -113,9 +115,9 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False):
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
         if c is not None:
             ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], shift=sh2, scale=sc2, gate=g2,
-                              mod_sample_stride=s2, rows_per_sample=rps)
+                              mod_sample_stride=s2, rows_per_sample=rps, x_bf16_out=x_bf16_out)
         else:
-            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1])
+            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1], x_bf16_out=x_bf16_out)
         return x
     if c is not None:
         h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
@@ -124,6 +126,8 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False):
     u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
     ops.gemm_bf16(u, P["wdn"], P["bdn"], EPI_RESID_F32, out=x, resid=x, gate=g2,
                   gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=rps)
+    if x_bf16_out is not None:
+        x_bf16_out.copy_(ops.cast_pad_bf16(x, x_bf16_out.shape[1]))
     return x
 
 

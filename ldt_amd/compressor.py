@@ -310,11 +310,11 @@ class Compressor(nn.Module):
         km = keep_mask.to(prior.device)
         return torch.stack([prior[km[b]] for b in range(Bc)], 0).reshape(Bc * num_points, -1).contiguous()
 
-    def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None):
+    def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None, o_bf16=None):
         """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j), c); c = label embedding in a class-conditional
         forward, None in `sample` (which never passes one, :263-264: the block then runs its plain-LayerNorm branch)."""
         zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
-        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c)
+        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c, x_bf16_out=o_bf16)
 
     def _decode_chunk(self, P, eps, N, keep_mask, seed_eps=None):
         Bc, T, _ = eps.shape
@@ -398,19 +398,21 @@ class Compressor(nn.Module):
         o = self._initial_set(P, B, npts, keep_mask, seed_eps)
         all_eps = torch.empty((B * T, L * z), dtype=torch.float32, device=dev)
         stats = []
+        # bf16 image of o for the next level's att(x, o): written by the decoder block's last kernel, not by a pass of its own
+        o_bf = torch.empty((B * npts, D), dtype=torch.bfloat16, device=dev) if (L > 1 and D % 64 == 0) else None
         for j in range(L):
             Pd = P["dec"][L - 1 - j]
             xj = enc_out[-j - 1].clone()
             if j == 0:
                 y, nk = ops.cast_pad_bf16(xj, ops.pad64(D)), T                       # compute_posterior(x, None): att(x, x)
-            else:
-                y, nk = ops.cast_pad_bf16(o, ops.pad64(D)), npts                    # att(x, o): K/V = 2048 decoded points
+            else:                                                                   # att(x, o): K/V = 2048 decoded points
+                y, nk = (o_bf if o_bf is not None else ops.cast_pad_bf16(o, ops.pad64(D))), npts
             residual_block(Pd["att"], xj, B, T, y_bf16=y, Nk=nk, c=l_emb)
             post = ops.sgemm(xj, Pd["w_prior"], Pd["b_prior"], act_in=ACT_SILU)      # SiLU -> Conv1d D -> 2z
             nz = post_noise[j].to(dev, torch.float32).contiguous().view(B * T, z)
             ej = all_eps[:, z * j: z * (j + 1)]
             stats.append(ops.reparam(post, nz, ej, self.min_sigma, 10., want_stats))
-            self._decoder_level(Pd, o, ej, B, npts, T, c=l_emb)
+            self._decoder_level(Pd, o, ej, B, npts, T, c=l_emb, o_bf16=o_bf if j + 1 < L else None)
         out = ops.sgemm(o, P["w_out"], P["b_out"]).view(B, npts, 3)
         res = {"set": self.postprocess(out), "all_eps": all_eps.view(B, T, L * z), "max": tok.max(),
                "posteriors": [(all_eps.view(B, T, L * z)[..., z * j: z * (j + 1)],) + tuple(

@@ -184,9 +184,10 @@ extern "C" int ldt_chamfer(const float* a, const float* b, int32_t B, int32_t na
 extern "C" int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
                                 const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
                                 int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
-                                const float* b_dn, void* stream) {
+                                const float* b_dn, uint16_t* x_bf16, int64_t ldxb, void* stream) {
     LDT_REQUIRE(x && w_up && b_up && w_dn && b_dn, LDT_EARG, "ln_mlp: null pointer");
-    MlpArgs a{x, ldx, M, ln_w, ln_b, shift, scale, gate, mod_sample_stride, rows_per_sample, BF(w_up), b_up, BF(w_dn), b_dn};
+    MlpArgs a{x, ldx, M, ln_w, ln_b, shift, scale, gate, mod_sample_stride, rows_per_sample, BF(w_up), b_up, BF(w_dn), b_dn,
+              BFM(x_bf16), ldxb};
     return ldt_ln_mlp_launch(&a, C, ST(stream));
 }
 extern "C" int ldt_ln_linear(const float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,

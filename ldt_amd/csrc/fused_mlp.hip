@@ -254,10 +254,21 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xo[j] = xo[j] + g4[j] * (oacc[n][rt][j] + b4[j]);
                 *reinterpret_cast<f32x4*>(xr + col) = xo;
+                oacc[n][rt] = xo;
             }
         } else {                                                       // the accumulators started from x + b_dn
 #pragma unroll
             for (int n = 0; n < C / 16; ++n) *reinterpret_cast<f32x4*>(xr + n * 16 + lq * 4) = oacc[n][rt];
+        }
+        if (a.x_bf16) {                                                // bf16 copy for the block that reads x as its K/V source
+            bf16_t* xb = a.x_bf16 + grow * a.ldxb;
+#pragma unroll
+            for (int n = 0; n < C / 16; ++n) {
+                bf16x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = (bf16_t)oacc[n][rt][j];
+                *reinterpret_cast<bf16x4*>(xb + n * 16 + lq * 4) = o4;
+            }
         }
     }
 }
@@ -360,6 +371,8 @@ int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st) {
                 (!a->ln_w || (ldt_aligned16(a->ln_w) && ldt_aligned16(a->ln_b))) &&
                 (!a->shift || (ldt_aligned16(a->shift) && ldt_aligned16(a->scale))) && (!a->gate || ldt_aligned16(a->gate)),
                 LDT_EALIGN, "ln_mlp: operands must be 16-byte aligned");
+    LDT_REQUIRE(!a->x_bf16 || (a->ldxb >= C && a->ldxb % 4 == 0 && (reinterpret_cast<uintptr_t>(a->x_bf16) & 7) == 0), LDT_EALIGN,
+                "ln_mlp: bf16 mirror rows must be 8-byte aligned");
     if (a->gate) return C == 128 ? launch_mlp<128, true>(a, st) : launch_mlp<64, true>(a, st);
     return C == 128 ? launch_mlp<128, false>(a, st) : launch_mlp<64, false>(a, st);
 }

@@ -104,6 +104,7 @@ struct MlpArgs {
     long mod_sample_stride; int rows_per_sample;
     const bf16_t* w_up; const float* b_up;             // [4C][C], [4C]
     const bf16_t* w_dn; const float* b_dn;             // [C][4C], [C]
+    bf16_t* x_bf16; long ldxb;                          // optional bf16 mirror of the updated x (the next block's K/V source) or null
 };
 int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st);
 // fused LayerNorm + linear (bf16 out) for narrow blocks (fused_mlp.hip)

@@ -309,14 +309,20 @@ def emd_approx(x, y, pairwise=False):
 
 
 def ln_mlp_resid_(x, w_up, b_up, w_dn, b_dn, ln_w=None, ln_b=None, shift=None, scale=None, gate=None,
-                  mod_sample_stride=0, rows_per_sample=0):
-    """In place: x += gate * MLP(LN(x)[affine | modulated]) for C in {64, 128} channels (one fused kernel)."""
+                  mod_sample_stride=0, rows_per_sample=0, x_bf16_out=None):
+    """In place: x += gate * MLP(LN(x)[affine | modulated]) for C in {64, 128} channels (one fused kernel).
+    x_bf16_out: optional bf16 [M, >=C] row-major tensor that receives a copy of the updated x in the same pass."""
     _need(x, torch.float32, "x"); _rowmajor(x, "x")
     M, Cc = x.shape
+    if x_bf16_out is not None:
+        _need(x_bf16_out, torch.bfloat16, "x_bf16_out"); _rowmajor(x_bf16_out, "x_bf16_out")
+        if x_bf16_out.shape[0] != M or x_bf16_out.shape[1] < Cc:
+            raise ValueError("ln_mlp_resid_: x_bf16_out must be [M, >=C]")
     if tuple(w_up.shape) != (4 * Cc, Cc) or tuple(w_dn.shape) != (Cc, 4 * Cc) or not (w_up.is_contiguous() and w_dn.is_contiguous()):
         raise ValueError("ln_mlp_resid_: weights must be dense bf16 [4C][C] and [C][4C]")
     check(lib().ldt_ln_mlp_resid(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
-                                 rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), stream_ptr()), "ldt_ln_mlp_resid")
+                                 rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), _p(x_bf16_out),
+                                 0 if x_bf16_out is None else x_bf16_out.stride(0), stream_ptr()), "ldt_ln_mlp_resid")
     return x
 
 

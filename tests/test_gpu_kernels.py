@@ -334,10 +334,13 @@ def test_fused_ln_mlp_resid(C, M, mode):
     elif mode == "mod":
         md = mod.cuda()
         kw = dict(shift=md[:, :C], scale=md[:, C:2 * C], gate=md[:, 2 * C:], mod_sample_stride=3 * C, rows_per_sample=rps)
+    mirror = torch.full((M, C + 64), -7.0, device="cuda", dtype=torch.bfloat16)[:, :C] if M % 2 == 0 else None   # strided rows
     ops.ln_mlp_resid_(xd, w_up.cuda().to(torch.bfloat16).contiguous(), b_up.cuda(), w_dn.cuda().to(torch.bfloat16).contiguous(),
-                      b_dn.cuda(), **kw)
+                      b_dn.cuda(), x_bf16_out=mirror, **kw)
     got_upd = xd.cpu() - x
     assert rel_mse(got_upd, upd) < 1e-4
+    if mirror is not None:                      # the bf16 copy written in the same pass == a cast of the fp32 result, bit for bit
+        assert torch.equal(mirror, xd.to(torch.bfloat16))
     with pytest.raises(Exception):
         ops.ln_mlp_resid_(torch.zeros(8, 96, device="cuda"), torch.zeros(384, 96, device="cuda", dtype=torch.bfloat16),
                           torch.zeros(384, device="cuda"), torch.zeros(96, 384, device="cuda", dtype=torch.bfloat16), torch.zeros(96, device="cuda"))
