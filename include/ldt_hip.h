@@ -185,6 +185,18 @@ int ldt_group_normalize(const float* feat, const float* xyz, const int32_t* fps_
                         int32_t k, int32_t D, uint16_t* U, int32_t ldu, int32_t center_mode, float* group_mean,
                         void* stream);
 int ldt_gather_rows(const float* src, const int32_t* idx, int32_t B, int32_t n, int32_t S, int32_t C, float* out, void* stream);
+/* Grouping + PreExtraction + neighbour max in ONE kernel (Compressor/layers.py:288-319 LocalGrouper.forward with
+ * normalize='anchor', :115-160 PreExtraction, :186 max over the k neighbours): out fp32 [B*S][128] = max_j relu(W3 . relu(W2 . h1 + b2)
+ * + b3 + h1), h1 = relu(W1 . u_j + b1), u_j = the grouped row [alpha*((g_j - anchor)/(std+1e-5)) + beta | anchor features] that
+ * ldt_group_normalize would write (never materialised here).  D must be 128, k one of 8, 16 or a multiple of 32.  stats: workspace double[2B].
+ * wimg: the three eval-BatchNorm-folded weight panels as bf16 MFMA fragments, 132 x 1 KB:
+ *   fragment f, lane l = 32 h + i, slot e (0..7)  ->  W[32 blk + i][col(step, h, e)]
+ *   layer 1  f = 4 step + blk, step 0..16: col = 16 step + 8 h + e (steps 0..7: normalised features), 131 + 16 (step - 8) + 8 h + e
+ *            (steps 8..15: anchor features), step 16: 128 + e for h = 0, e < 3 (xyz), zero weight elsewhere;
+ *   layer 2  f = 68 + 4 step + blk,  layer 3  f = 100 + 4 step + blk, step 0..7: col = 16 step + 8 (e >> 2) + 4 h + (e & 3). */
+int ldt_grouper_mlp(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx, const float* alpha,
+                    const float* beta, double* stats, int32_t B, int32_t n, int32_t S, int32_t k, int32_t D,
+                    const uint16_t* wimg, const float* b1, const float* b2, const float* b3, float* out, void* stream);
 int ldt_maxpool(const void* in, int32_t in_bf16, int64_t ld, int64_t G, int32_t n, int32_t C, float* out, void* stream);
 int ldt_actnorm(float* x, const float* shift, const float* log_scale, int64_t B, int64_t per_sample, void* stream);
 int ldt_reparam(const float* post, const float* noise, float* out, int64_t ldo, float* mu_out, float* logvar_out,

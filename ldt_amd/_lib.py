@@ -71,6 +71,7 @@ SIGNATURES = {
     "ldt_actnorm": [_vp, _vp, _vp, _i64, _i64, _vp],
     "ldt_reparam": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, C.c_float, C.c_float, _vp],
     "ldt_chamfer": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ldt_grouper_mlp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ldt_ln_mlp_resid": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "ldt_ln_linear": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     "ldt_chamfer_pairwise": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

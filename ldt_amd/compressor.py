@@ -5,6 +5,8 @@ Same constructor / parameter tree / methods as the reference: `forward(x)` (= en
 Network.py:235-249), `sample(shape, given_eps)` (= decode, :251-268), `init()` (:163-165), plus the aliases
 `encode` / `decode` that BASELINE.json's north-star names.  All arithmetic runs in libldt_hip.so.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -79,8 +81,37 @@ class LocalGrouper(_Holder):
         G["w_pre1"], G["b_pre1"] = _bf16_panel(w1), b1
         w2, b2 = _fold_bn(ex.operation[0].net1[0], ex.operation[0].net1[1])
         G["w_pre2"], G["b_pre2"] = _bf16_panel(w2), b2
-        G["w_pre3"], G["b_pre3"] = _bf16_panel(f32(conv_w(ex.operation[0].net2[0]))), f32(ex.operation[0].net2[0].bias)
+        w3 = f32(conv_w(ex.operation[0].net2[0]))
+        G["w_pre3"], G["b_pre3"] = _bf16_panel(w3), f32(ex.operation[0].net2[0].bias)
+        if self.in_channels == 128 and self.normalize == "anchor" and w1.shape == (128, 259) and w2.shape == w3.shape == (128, 128):
+            G["wimg"] = _grouper_fragment_image(w1, w2, w3)             # operands of the one-kernel grouper
         return G
+
+
+def _grouper_fragment_image(w1, w2, w3):
+    """The three PreExtraction panels as the bf16 MFMA fragments `ldt_grouper_mlp` keeps in LDS (layout: include/ldt_hip.h):
+    [fragment][lane = 32 h + i][slot e] = W[32 blk + i][col(step, h, e)], zero where a layer-1 slot has no input column."""
+    dev = w1.device
+    h = torch.arange(2, device=dev).view(1, 2, 1)
+    e = torch.arange(8, device=dev).view(1, 1, 8)
+    s1 = torch.arange(17, device=dev).view(17, 1, 1)
+    col1 = torch.where(s1 < 8, 16 * s1 + 8 * h + e, 131 + 16 * (s1 - 8) + 8 * h + e)
+    col1 = torch.where(s1 == 16, torch.where((h == 0) & (e < 3), 128 + e, torch.full_like(col1, -1)), col1)
+    s2 = torch.arange(8, device=dev).view(8, 1, 1)
+    col2 = 16 * s2 + 8 * (e // 4) + 4 * h + (e % 4)
+
+    def frags(w, col):                                                   # w [128, K], col [steps, 2, 8] (-1: no input)
+        wz = torch.cat([w, torch.zeros((128, 1), device=dev, dtype=w.dtype)], 1)
+        c = torch.where(col < 0, torch.full_like(col, w.shape[1]), col)
+        img = wz[:, c.reshape(-1)].view(4, 32, col.shape[0], 2, 8)       # [blk, i, step, h, e]
+        return img.permute(2, 0, 3, 1, 4).reshape(-1)                    # [step, blk, h, i, e]
+
+    img = torch.cat([frags(w1, col1), frags(w2, col2), frags(w3, col2)]).to(torch.bfloat16).contiguous()
+    assert img.numel() == ops.GROUPER_FRAGS * 512
+    return img
+
+
+FUSED_GROUPER = os.environ.get("LDT_FUSED_GROUPER", "1") != "0"          # 0: the five-kernel chain (A/B runs, parity tests)
 
 
 def run_grouper(G, pts, feat, groups, k):
@@ -92,6 +123,11 @@ def run_grouper(G, pts, feat, groups, k):
     fps_idx = ops.fps(pts, groups)
     centers = ops.gather_rows(pts, fps_idx)                                     # [B,S,3]
     knn_idx = ops.knn(pts, centers, k)
+    if FUSED_GROUPER and "wimg" in G and (k in (8, 16) or k % 32 == 0) and feat.shape[2] == 128:
+        # grouped rows, the three pointwise layers and the max over neighbours in one kernel: no [B*S*k, .] tensor exists
+        tok = ops.grouper_mlp(feat.contiguous(), pts.contiguous(), fps_idx, knn_idx, G["alpha"], G["beta"], G["wimg"],
+                              G["b_pre1"], G["b_pre2"], G["b_pre3"])
+        return centers, tok, fps_idx, knn_idx
     U = ops.group_normalize(feat, pts, fps_idx, knn_idx, G["alpha"], G["beta"], normalize=G["normalize"])
     h1 = ops.gemm_bf16(U, G["w_pre1"], G["b_pre1"], EPI_RELU_BF16)              # transfer: Conv+BN+ReLU
     r = ops.gemm_bf16(h1, G["w_pre2"], G["b_pre2"], EPI_RELU_BF16)              # net1: Conv+BN+ReLU

@@ -150,6 +150,16 @@ extern "C" int ldt_group_normalize(const float* feat, const float* xyz, const in
     return ldt_group_launch(feat, xyz, fps_idx, knn_idx, alpha, beta, stats, B, n, S, k, D, BFM(U), ldu, center_mode, group_mean,
                             ST(stream));
 }
+extern "C" int ldt_grouper_mlp(const float* feat, const float* xyz, const int32_t* fps_idx, const int32_t* knn_idx, const float* alpha,
+                               const float* beta, double* stats, int32_t B, int32_t n, int32_t S, int32_t k, int32_t D,
+                               const uint16_t* wimg, const float* b1, const float* b2, const float* b3, float* out, void* stream) {
+    LDT_REQUIRE(feat && xyz && fps_idx && knn_idx && alpha && beta && stats && wimg && b1 && b2 && b3 && out, LDT_EARG, "grouper_mlp: null pointer");
+    LDT_REQUIRE(D == 128, LDT_ESHAPE, "grouper_mlp: the fused kernel is built for 128 channels (got D=%d)", D);
+    const int rc = ldt_group_stats_launch(feat, xyz, fps_idx, knn_idx, stats, B, n, S, k, D, ST(stream));
+    if (rc != LDT_OK) return rc;
+    GroupMlpArgs a{feat, xyz, fps_idx, knn_idx, alpha, beta, stats, BF(wimg), b1, b2, b3, B, n, S, k, 0, out};
+    return ldt_grouper_mlp_launch(&a, ST(stream));
+}
 extern "C" int ldt_norm_points(const float* xyz, int32_t B, int32_t n, float* out, void* stream) {
     LDT_REQUIRE(xyz && out, LDT_EARG, "norm_points: null pointer");
     return ldt_norm_points_launch(xyz, B, n, out, ST(stream));

@@ -87,6 +87,20 @@ int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, 
 int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
                      const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu,
                      int center_mode, float* gmean, hipStream_t s);
+int ldt_group_stats_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, double* stats,
+                           int B, int n, int S, int k, int D, hipStream_t s);
+// grouping + PreExtraction + neighbour max in one kernel (grouper_mlp.hip): D = 128 channels, k in {8, 16, 32 m}, 'anchor' mode
+struct GroupMlpArgs {
+    const float* feat; const float* xyz;               // [B][n][128], [B][n][3]
+    const int* fps_idx; const int* knn_idx;            // [B][S], [B][S][k]
+    const float* alpha; const float* beta;             // [131]
+    const double* stats;                               // [2B] from ldt_group_stats_launch
+    const bf16_t* wimg;                                // MFMA fragment image of the three weight panels (132 x 1 KB)
+    const float* b1; const float* b2; const float* b3; // [128] each
+    int B, n, S, k, flat;
+    float* out;                                        // [B*S][128]
+};
+int ldt_grouper_mlp_launch(const GroupMlpArgs* a, hipStream_t s);
 int ldt_norm_points_launch(const float* xyz, int B, int n, float* out, hipStream_t s);
 int ldt_mixture_seed_launch(const float* eps, const float* sig, const float* mu, const float* logits, int n_mix, int D, long rows, float* out, hipStream_t s);
 int ldt_gather_rows_launch(const float* src, const int* idx, int B, int n, int S, int C, float* out, hipStream_t s);

@@ -319,16 +319,31 @@ __global__ __launch_bounds__(256) void group_build_kernel(const float* __restric
     }
 }
 
+// per-sample sums of (g - anchor) and its square over all grouped rows ('anchor' normalisation): stats[2b], stats[2b+1]
+int ldt_group_stats_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, double* stats,
+                           int B, int n, int S, int k, int D, hipStream_t s) {
+    LDT_REQUIRE(B > 0 && n > 0 && S > 0 && k > 0 && D > 0, LDT_ESHAPE, "group_stats: bad shape");
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s);
+    if (e != hipSuccess) { ldt_set_error("group: memset: %s", hipGetErrorString(e)); return (int)e; }
+    const long rows = (long)S * k;
+    int bx = (int)((rows + 3) / 4); if (bx > 256) bx = 256;
+    int gx = (S + 3) / 4; if (gx > 64) gx = 64;
+    if (D == 128 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<32>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
+    else if (D == 64 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<16>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
+    else hipLaunchKernelGGL(group_stats_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, nullptr, n, S, k, D, stats);
+    return ldt_check_launch("group_stats");
+}
+
 int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
                      const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu,
                      int center_mode, float* gmean, hipStream_t s) {
     LDT_REQUIRE(B > 0 && n > 0 && S > 0 && k > 0 && D > 0 && ldu >= 2 * D + 3, LDT_ESHAPE, "group: bad shape");
     LDT_REQUIRE(center_mode == 0 || (center_mode == 1 && gmean), LDT_EARG, "group: mode 1 ('center') needs the group-mean workspace");
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s);
-    if (e != hipSuccess) { ldt_set_error("group: memset: %s", hipGetErrorString(e)); return (int)e; }
     const long rows = (long)S * k;
     int bx = (int)((rows + 3) / 4); if (bx > 256) bx = 256;
     if (center_mode) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, s);
+        if (e != hipSuccess) { ldt_set_error("group: memset: %s", hipGetErrorString(e)); return (int)e; }
         long mb = ((long)S * (D + 3) + 255) / 256; if (mb > 1024) mb = 1024;
         hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)mb, B), dim3(256), 0, s, feat, xyz, knn_idx, n, S, k, D, gmean);
         TRY_LAUNCH("group_mean");
@@ -337,11 +352,8 @@ int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, co
         hipLaunchKernelGGL(group_build_kernel<true>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, gmean, n, S, k, D, U, ldu);
         return ldt_check_launch("group_build");
     }
-    int gx = (S + 3) / 4; if (gx > 64) gx = 64;
-    if (D == 128 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<32>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
-    else if (D == 64 && ldt_aligned16(feat)) hipLaunchKernelGGL(group_stats_vec_kernel<16>, dim3(gx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, n, S, k, stats);
-    else hipLaunchKernelGGL(group_stats_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, nullptr, n, S, k, D, stats);
-    TRY_LAUNCH("group_stats");
+    const int st = ldt_group_stats_launch(feat, xyz, fps_idx, knn_idx, stats, B, n, S, k, D, s);
+    if (st != LDT_OK) return st;
     hipLaunchKernelGGL(group_build_kernel<false>, dim3(bx, B), dim3(256), 0, s, feat, xyz, fps_idx, knn_idx, alpha, beta, stats, nullptr, n, S, k, D, U, ldu);
     return ldt_check_launch("group_build");
 }

@@ -240,6 +240,29 @@ def group_normalize(feat, xyz, fps_idx, knn_idx, alpha, beta, normalize="anchor"
     return U
 
 
+GROUPER_FRAGS = 132                                      # 1 KB MFMA fragments in the fused grouper's weight image
+
+
+def grouper_mlp(feat, xyz, fps_idx, knn_idx, alpha, beta, wimg, b1, b2, b3):
+    """Grouping ('anchor' normalisation) + PreExtraction + max over the k neighbours (k = 8, 16 or a multiple of 32) in one
+    kernel: feat fp32 [B,n,128], xyz [B,n,3], fps_idx [B,S], knn_idx [B,S,k] -> fp32 [B*S, 128].  wimg: bf16 fragment image
+    (include/ldt_hip.h: ldt_grouper_mlp) built by LocalGrouper.pack."""
+    B, n, D = feat.shape
+    S, k = knn_idx.shape[1], knn_idx.shape[2]
+    for t, nm in ((feat, "feat"), (xyz, "xyz"), (alpha, "alpha"), (beta, "beta"), (b1, "b1"), (b2, "b2"), (b3, "b3")):
+        _need(t, torch.float32, nm)
+    _need(wimg, torch.bfloat16, "wimg")
+    if not (feat.is_contiguous() and xyz.is_contiguous() and fps_idx.is_contiguous() and knn_idx.is_contiguous() and wimg.is_contiguous()):
+        raise ValueError("grouper_mlp: operands must be contiguous")
+    if wimg.numel() != GROUPER_FRAGS * 512 or alpha.numel() != D + 3 or beta.numel() != D + 3 or min(b1.numel(), b2.numel(), b3.numel()) < D:
+        raise ValueError("grouper_mlp: weight image / affine vectors have the wrong size")
+    out = torch.empty((B * S, D), dtype=torch.float32, device=feat.device)
+    stats = torch.empty((2 * B,), dtype=torch.float64, device=feat.device)
+    check(lib().ldt_grouper_mlp(_p(feat), _p(xyz), _p(fps_idx), _p(knn_idx), _p(alpha), _p(beta), _p(stats), B, n, S, k, D,
+                                _p(wimg), _p(b1), _p(b2), _p(b3), _p(out), stream_ptr()), "ldt_grouper_mlp")
+    return out
+
+
 def gather_rows(src, idx):
     """src fp32 [B,n,C], idx int32 [B,S] -> [B,S,C]."""
     B, n, Cc = src.shape

@@ -256,3 +256,38 @@ def test_compressor_options_golden(tiny_cfg):
     comp.reference_rng = False
     d1 = comp.sample((2, 48), given_eps=a["b_given_eps"].cuda())    # device Philox seed rows: finite, different draw
     assert bool(torch.isfinite(d1).all()) and not torch.equal(d1, dec)
+
+
+@pytest.mark.parametrize("B,n,S,k", [(2, 512, 24, 32), (17, 256, 40, 16), (1, 64, 3, 32), (3, 512, 7, 16), (2, 2048, 32, 128),
+                                     (16, 300, 5, 8), (2, 256, 9, 64)])
+def test_fused_grouper_vs_oracle_and_chain(mods, B, n, S, k):
+    """The one-kernel grouper (grouping + PreExtraction + neighbour max, D = 128) against the oracle's local_grouper (fp32)
+    and against the five-kernel chain it replaces — every tile shape (k = 8 / 16: 4 / 2 groups per MFMA tile, k = 32 m: m tiles
+    per group; the shipped encoders use k = 16 and k = 128), both cloud-to-XCD mappings (B < 16: flat), ragged group counts,
+    non-trivial BatchNorm statistics."""
+    ops, O = mods
+    from ldt_amd import compressor as Cm
+    D = 128
+    torch.manual_seed(100 + B)
+    grp = Cm.LocalGrouper(D)
+    with torch.no_grad():
+        grp.affine_alpha.uniform_(0.5, 1.5); grp.affine_beta.normal_(0, 0.2)
+        for bn in (grp.extraction.transfer.net[1], grp.extraction.operation[0].net1[1]):
+            bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    sd = {"g." + kk: v.detach().clone() for kk, v in grp.state_dict().items()}
+    p = unit_clouds(B, n, 31 + B)
+    feat = torch.randn(B, n, D, generator=torch.Generator().manual_seed(B)) * 0.7
+    _, ref, fi, ki = O.local_grouper(sd, "g", p, feat, S, k)
+    G = grp.cuda().pack()
+    assert "wimg" in G
+    fused = Cm.run_grouper(G, p.cuda(), feat.cuda(), S, k)
+    assert torch.equal(fused[2].cpu().long(), fi.long())
+    assert rel_mse(fused[1].view(B, S, D).cpu(), ref) < 1e-4
+    try:
+        Cm.FUSED_GROUPER = False
+        chain = Cm.run_grouper(G, p.cuda(), feat.cuda(), S, k)
+    finally:
+        Cm.FUSED_GROUPER = True
+    # same bf16 operands and roundings, another summation order: equal up to a bf16 ulp on a few elements
+    assert rel_mse(fused[1], chain[1]) < 1e-5
+    assert float((fused[1] != chain[1]).float().mean()) < 0.25
