@@ -72,23 +72,33 @@ __global__ __launch_bounds__(512) void grouper_mlp_kernel(const GroupMlpArgs a) 
 #pragma unroll
         for (int e = 0; e < 8; ++e) idf[t][e] = (bf16_t)((j == 16 * t + 8 * (e >> 2) + 4 * h + (e & 3)) ? 1.f : 0.f);
 
-    // clouds b = xcd, xcd + 8, ... belong to the WGs of one XCD (WG x runs on XCD x % 8); its waves split the cloud's groups
-    const int xcd = blockIdx.x & 7, wpx = (gridDim.x >> 3) * 8;            // waves per XCD
-    const int w0 = (blockIdx.x >> 3) * 8 + wave;
-    const int K = a.k, tpg = GPT == 1 ? K / 32 : 1;                        // tiles per work item (= one group, or GPT groups in one tile)
-    const int items = (a.S + GPT - 1) / GPT;
-    const long rows = (long)a.S * K;
-    for (int b = a.flat ? 0 : xcd; b < a.B; b += a.flat ? 1 : 8) {
-        const double cnt = (double)rows * 131.0;
-        const double mean = a.stats[2 * b] / cnt;
-        const double var = (a.stats[2 * b + 1] - cnt * mean * mean) / (cnt - 1.0);
-        const float inv = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-5f);
-        const float* featb = a.feat + (long)b * a.n * 128;
-        const float* xyzb = a.xyz + (long)b * a.n * 3;
-        for (int item = a.flat ? blockIdx.x * 8 + wave : w0; item < items; item += a.flat ? gridDim.x * 8 : wpx) {
-          float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};    // running max over the group's tiles (GPT == 1)
-          for (int tile = 0; tile < tpg; ++tile) {
-            int sidx = GPT == 1 ? item : item * GPT + j / (32 / GPT);      // a ragged last tile repeats the last group (never stored)
+    // Work items = 32-row tiles.  Clouds b = xcd, xcd + 8, ... belong to the WGs of one XCD (WG x runs on XCD x % 8): its waves
+    // walk that list of clouds tile by tile, so an XCD's L2 holds one or two clouds' features at a time.  With few clouds
+    // (a.flat) every cloud is spread over all XCDs instead.
+    const int xcd = blockIdx.x & 7;
+    const int nw = a.flat ? gridDim.x * 8 : (gridDim.x >> 3) * 8;          // waves sharing one work list
+    const int w0 = a.flat ? blockIdx.x * 8 + wave : (blockIdx.x >> 3) * 8 + wave;
+    const int K = a.k, tpg = GPT == 1 ? K / 32 : 1;                        // tiles per group (GPT == 1) / GPT groups per tile
+    const int items = GPT == 1 ? a.S * tpg : (a.S + GPT - 1) / GPT;        // tiles per cloud
+    const int nclouds = a.flat ? a.B : (a.B - xcd + 7) / 8;
+    const long total = (long)nclouds * items;
+    const double cnt = (double)a.S * K * 131.0;
+    int b_prev = -1;
+    float inv = 0.f;
+    for (long f = w0; f < total; f += nw) {
+        {
+            const int cl = (int)(f / items), item = (int)(f - (long)cl * items);
+            const int b = a.flat ? cl : xcd + 8 * cl;
+            if (b != b_prev) {                                             // per-sample unbiased std of (g - anchor), layers.py:311-312
+                const double mean = a.stats[2 * b] / cnt;
+                const double var = (a.stats[2 * b + 1] - cnt * mean * mean) / (cnt - 1.0);
+                inv = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-5f);
+                b_prev = b;
+            }
+            const float* featb = a.feat + (long)b * a.n * 128;
+            const float* xyzb = a.xyz + (long)b * a.n * 3;
+            const int tile = GPT == 1 ? item % tpg : 0;
+            int sidx = GPT == 1 ? item / tpg : item * GPT + j / (32 / GPT);   // a ragged last tile repeats the last group (never stored)
             if (GPT > 1 && sidx >= a.S) sidx = a.S - 1;
             const int nb = GPT == 1 ? tile * 32 + j : j % (32 / GPT);
             const long g = (long)b * a.S + sidx;
@@ -107,19 +117,33 @@ __global__ __launch_bounds__(512) void grouper_mlp_kernel(const GroupMlpArgs a) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[blk][4 * q + r] = b4[r];
                 }
+            // every gathered row of the tile is requested before the first MFMA: one memory latency per tile, not one per k-step
+            f32x4 gq[8][2], aq[8][2];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                gq[s][0] = *reinterpret_cast<const f32x4*>(fg + 16 * s); gq[s][1] = *reinterpret_cast<const f32x4*>(fg + 16 * s + 4);
+                aq[s][0] = *reinterpret_cast<const f32x4*>(fa + 16 * s); aq[s][1] = *reinterpret_cast<const f32x4*>(fa + 16 * s + 4);
+            }
+            float xg[3] = {0.f, 0.f, 0.f}, xa[3] = {0.f, 0.f, 0.f};
+            if (h == 0) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { xg[e] = xyzb[(long)pi * 3 + e]; xa[e] = xyzb[(long)ci * 3 + e]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[8];                                                  // the anchor's own features (k-steps 8..15), kept as bf16
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                                  // alpha * ((g - anchor) * inv) + beta, feature channels
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(fg + 16 * s), g1 = *reinterpret_cast<const f32x4*>(fg + 16 * s + 4);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(fa + 16 * s), a1 = *reinterpret_cast<const f32x4*>(fa + 16 * s + 4);
                 const f32x4 al0 = *reinterpret_cast<const f32x4*>(alpha + 16 * s + 8 * h), al1 = *reinterpret_cast<const f32x4*>(alpha + 16 * s + 8 * h + 4);
                 const f32x4 be0 = *reinterpret_cast<const f32x4*>(beta + 16 * s + 8 * h), be1 = *reinterpret_cast<const f32x4*>(beta + 16 * s + 8 * h + 4);
-                float v[8];
+                float v[8], w[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = al0[e] * ((g0[e] - a0[e]) * inv) + be0[e];
-                    v[4 + e] = al1[e] * ((g1[e] - a1[e]) * inv) + be1[e];
+                    v[e] = al0[e] * ((gq[s][0][e] - aq[s][0][e]) * inv) + be0[e];
+                    v[4 + e] = al1[e] * ((gq[s][1][e] - aq[s][1][e]) * inv) + be1[e];
+                    w[e] = aq[s][0][e]; w[4 + e] = aq[s][1][e];
                 }
                 const bf16x8 uf = to_bf16x8(v);
+                af[s] = to_bf16x8(w);
 #pragma unroll
                 for (int blk = 0; blk < 4; ++blk)
                     acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Wl + (s * 4 + blk) * 1024), uf, acc[blk], 0, 0, 0);
@@ -127,19 +151,16 @@ __global__ __launch_bounds__(512) void grouper_mlp_kernel(const GroupMlpArgs a) 
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {                                  // the anchor's own features, repeated on every row
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(fa + 16 * s), a1 = *reinterpret_cast<const f32x4*>(fa + 16 * s + 4);
-                const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const bf16x8 uf = to_bf16x8(v);
 #pragma unroll
                 for (int blk = 0; blk < 4; ++blk)
-                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Wl + ((8 + s) * 4 + blk) * 1024), uf, acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Wl + ((8 + s) * 4 + blk) * 1024), af[s], acc[blk], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             {                                                              // normalised xyz offsets: 3 live k-slots on the lower half
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (h == 0) {
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) v[e] = alpha[128 + e] * ((xyzb[(long)pi * 3 + e] - xyzb[(long)ci * 3 + e]) * inv) + beta[128 + e];
+                    for (int e = 0; e < 3; ++e) v[e] = alpha[128 + e] * ((xg[e] - xa[e]) * inv) + beta[128 + e];
                 }
                 const bf16x8 uf = to_bf16x8(v);
 #pragma unroll
@@ -191,39 +212,26 @@ __global__ __launch_bounds__(512) void grouper_mlp_kernel(const GroupMlpArgs a) 
                 for (int t = 0; t < 2; ++t) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1[2 * blk + t], idf[t], acc[blk], 0, 0, 0);
 
             // ---- max over the neighbours, ReLU, bf16 rounding (both monotone: applied once, after the max) ----------------
-            if (GPT == 1) {
+            constexpr int RPG = 16 / GPT;                                  // accumulator registers per group and half:
+#pragma unroll                                                             // group q = tile rows [q k, (q + 1) k) = registers [q RPG, (q + 1) RPG)
+            for (int q = 0; q < GPT; ++q) {
+                const int so = GPT == 1 ? sidx : item * GPT + q;
 #pragma unroll
                 for (int blk = 0; blk < 4; ++blk) {
-                    float m = acc[blk][0];
+                    float m = acc[blk][q * RPG];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[blk][r]);
-                    mrun[blk] = fmaxf(mrun[blk], m);
-                }
-            } else {                                                       // group q = tile rows [q k, (q + 1) k) = registers [q RPG, (q + 1) RPG) of both halves
-                constexpr int RPG = 16 / GPT;                              // accumulator registers per group and half
-#pragma unroll
-                for (int q = 0; q < GPT; ++q) {
-                    const int so = item * GPT + q;
-#pragma unroll
-                    for (int blk = 0; blk < 4; ++blk) {
-                        float m = acc[blk][q * RPG];
-#pragma unroll
-                        for (int r = 1; r < RPG; ++r) m = fmaxf(m, acc[blk][q * RPG + r]);
-                        m = fmaxf(m, __shfl_xor(m, 32, 64));
-                        m = (float)(bf16_t)fmaxf(m, 0.f);
-                        if (h == 0 && so < a.S) a.out[((long)b * a.S + so) * 128 + blk * 32 + j] = m;
+                    for (int r = 1; r < RPG; ++r) m = fmaxf(m, acc[blk][q * RPG + r]);
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    m = (float)(bf16_t)fmaxf(m, 0.f);
+                    float* o = a.out + ((long)b * a.S + so) * 128 + blk * 32 + j;
+                    if (h == 0 && so < a.S) {
+                        // several tiles per group: the group's maximum is combined in memory (results are >= 0 after the ReLU:
+                        // their bit patterns order like integers; the launcher zeroes `out`)
+                        if (GPT == 1 && tpg > 1) atomicMax(reinterpret_cast<int*>(o), __float_as_int(m));
+                        else *o = m;
                     }
                 }
             }
-          }
-          if (GPT == 1) {
-#pragma unroll
-              for (int blk = 0; blk < 4; ++blk) {
-                  float m = fmaxf(mrun[blk], __shfl_xor(mrun[blk], 32, 64));
-                  m = (float)(bf16_t)fmaxf(m, 0.f);
-                  if (h == 0) a.out[((long)b * a.S + item) * 128 + blk * 32 + j] = m;
-              }
-          }
         }
     }
 }
@@ -243,7 +251,12 @@ int ldt_grouper_mlp_launch(const GroupMlpArgs* a, hipStream_t st) {
     const int gpt = a->k >= 32 ? 1 : 32 / a->k;
     int grid = cus / 8 * 8;
     if (grid < 8) grid = 8;
-    if (k.flat) { const int need = ((a->S + gpt - 1) / gpt + 7) / 8; if (grid > need) grid = need; }
+    const long tiles_per_cloud = gpt == 1 ? (long)a->S * (a->k / 32) : (a->S + gpt - 1) / gpt;
+    if (k.flat) { const long need = (a->B * tiles_per_cloud + 7) / 8; if (grid > need) grid = (int)need; }
+    if (a->k > 32) {                                            // tiles of one group meet in memory (atomicMax on results >= 0)
+        const hipError_t e = hipMemsetAsync(a->out, 0, sizeof(float) * (size_t)a->B * a->S * 128, st);
+        if (e != hipSuccess) { ldt_set_error("grouper_mlp: memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
 #define GF_LAUNCH(G)                                                                            \
     do {                                                                                        \
         LDT_ENSURE_LDS((grouper_mlp_kernel<G>), GF_LDS, "grouper_mlp");                         \

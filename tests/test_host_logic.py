@@ -303,3 +303,45 @@ def test_bench_traffic_provenance(tmp_path, monkeypatch):
     assert v is None and prov["status"].startswith("stale") and prov["collected_on_csrc_sha"] == "0" * 16
     v, prov = bench.measured_traffic("k<3>")
     assert v is None and "no measurement" in prov["status"]
+
+
+def test_grouper_fragment_image_layout():
+    """The fused grouper's weight image (include/ldt_hip.h: ldt_grouper_mlp) element by element: fragment f, lane 32 h + i,
+    slot e holds W[32 blk + i][col(step, h, e)] with the documented column maps, zero where layer 1 has no input."""
+    import torch
+    from ldt_amd.compressor import _grouper_fragment_image
+    g = torch.Generator().manual_seed(0)
+    w1, w2, w3 = torch.randn(128, 259, generator=g), torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g)
+    img = _grouper_fragment_image(w1, w2, w3).float().view(132, 64, 8)
+    bf = lambda t: t.to(torch.bfloat16).float()
+
+    def col1(step, h, e):
+        if step < 8:
+            return 16 * step + 8 * h + e
+        if step < 16:
+            return 131 + 16 * (step - 8) + 8 * h + e
+        return 128 + e if (h == 0 and e < 3) else None
+
+    col2 = lambda step, h, e: 16 * step + 8 * (e >> 2) + 4 * h + (e & 3)
+    seen1 = set()
+    for step in range(17):
+        for blk in range(4):
+            for h in range(2):
+                for e in range(8):
+                    c = col1(step, h, e)
+                    got = img[step * 4 + blk, 32 * h:32 * h + 32, e]
+                    want = torch.zeros(32) if c is None else bf(w1[32 * blk:32 * blk + 32, c])
+                    assert torch.equal(got, want)
+                    if c is not None:
+                        seen1.add(c)
+    assert seen1 == set(range(259))                                  # every input column of layer 1 is used exactly where expected
+    for base, w in ((68, w2), (100, w3)):
+        seen = set()
+        for step in range(8):
+            for blk in range(4):
+                for h in range(2):
+                    for e in range(8):
+                        c = col2(step, h, e)
+                        seen.add(c)
+                        assert torch.equal(img[base + step * 4 + blk, 32 * h:32 * h + 32, e], bf(w[32 * blk:32 * blk + 32, c]))
+        assert seen == set(range(128))
