@@ -336,7 +336,9 @@ int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s) {
     LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, LDT_ESHAPE, "sgemm: empty problem");
     LDT_REQUIRE(a->A && a->B && a->C, LDT_EARG, "sgemm: null pointer");
     static const bool no_mfma = getenv("LDT_SGEMM_VALU") != nullptr;      // tools/dbg A/B: force the scalar-FMA kernel
+    static const bool no_skinny = getenv("LDT_SGEMM_SKINNY") && atoi(getenv("LDT_SGEMM_SKINNY")) == 0;
     int st = LDT_OK;
+    if (!no_skinny && ldt_skinny_linear_try(a, s, &st)) return st;      // millions of rows x (K <= 32 | N <= 8): streaming forms (skinny_linear.hip)
     if (!no_mfma && ldt_sgemm_mfma_try(a, s, &st)) return st;            // fp32-input MFMA kernel (sgemm_mfma.hip) when rows are 16-B aligned, K % 16 == 0
     dim3 grid((a->N + 63) / 64, (a->M + 63) / 64), block(256);
     LDT_REQUIRE(grid.y < 65536, LDT_ESHAPE, "sgemm: M too large for this kernel (M=%d)", a->M);

@@ -81,6 +81,7 @@ int ldt_philox_normal_launch(float* out, long n, long elem_offset, int step, uin
 int ldt_sinusoid_launch(const float* t, const float* freq, float* e, int n, int half, hipStream_t s);
 int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s);
 bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status);   // sgemm_mfma.hip: false = shape not taken
+bool ldt_skinny_linear_try(const SgemmArgs* a, hipStream_t s, int* status);   // skinny_linear.hip
 
 int ldt_fps_launch(const float* xyz, int B, int n, int m, int skip_near_origin, int* idx, hipStream_t s);
 int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, int k, int* out, float* dist_out, hipStream_t s);

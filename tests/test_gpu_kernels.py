@@ -219,7 +219,9 @@ def test_layernorm_modulate(M, C):
 
 # ------------------------------------------------------------------------------------------- fp32 linears
 @pytest.mark.parametrize("M,N,K", [(5, 64, 3), (300, 128, 20), (1000, 768, 64), (7, 2048, 1024), (65, 40, 128), (130, 300, 256),
-                                   (32, 1000, 512), (1000, 2048, 1024), (4096, 40, 128), (2048, 128, 20)])
+                                   (32, 1000, 512), (1000, 2048, 1024), (4096, 40, 128), (2048, 128, 20),
+                                   # streaming forms (skinny_linear.hip): millions-of-rows convs of the Compressor, ragged tails
+                                   (20001, 128, 3), (16385, 128, 20), (9000, 64, 32), (30003, 3, 128), (8193, 8, 64), (10000, 1, 512)])
 def test_sgemm(M, N, K):
     from ldt_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU
     g = torch.Generator().manual_seed(K)
