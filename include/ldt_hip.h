@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 10
+#define LDT_ABI_VERSION 11
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -214,6 +214,18 @@ int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, const float* l
                      const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
                      int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
                      const float* b_dn, uint16_t* x_bf16, int64_t ldxb, void* stream);
+
+/* The same kernel followed, on the rows it has just produced, by the NEXT block's LayerNorm + first projection
+ * (model/layers.py:218 / :225 of the ResidualBlock that follows: nx_out bf16 [M][nx_ldo] = LN(x_new)[nx affine | nx modulated] . nx_w^T
+ * + nx_bias, nx_w bf16 [nx_N][C], nx_N a multiple of 64) — what ldt_ln_linear would compute from x_new in a pass of its own.  In the
+ * Compressor's decoder that is the next level's query projection (Network.py:80-83 via layers.py:225). */
+int ldt_ln_mlp_resid_next(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                          const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
+                          int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
+                          const float* b_dn, uint16_t* x_bf16, int64_t ldxb,
+                          const float* nx_ln_w, const float* nx_ln_b, const float* nx_shift, const float* nx_scale,
+                          int64_t nx_mod_sample_stride, int32_t nx_rows_per_sample, const uint16_t* nx_w, const float* nx_bias,
+                          int32_t nx_N, uint16_t* nx_out, int64_t nx_ldo, void* stream);
 
 /* LayerNorm + linear for the same narrow blocks: out bf16 [M][ldo] = LN(x)[affine | modulated] . W^T + bias, W bf16 [N][C]
  * dense, N % 64 == 0, C in {64, 128} — fc_q (and fc_kv when the block attends to its own normalised input,

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -73,6 +73,8 @@ SIGNATURES = {
     "ldt_chamfer": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ldt_grouper_mlp": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ldt_ln_mlp_resid": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "ldt_ln_mlp_resid_next": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
+                              _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     "ldt_ln_linear": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _vp],
     "ldt_chamfer_pairwise": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_emd_approx": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -53,13 +53,16 @@ def pack_block(blk):
     return P
 
 
-def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None):
+def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None, q_pre=None, next_P=None):
     """x fp32 [B*Nq, C] updated IN PLACE (and returned) when dim_out == dim_in; a NEW [B*Nq, dim_out] tensor is returned
     for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
     c: fp32 [B, dim_c] condition (AdaLN) — or [B*Nq, dim_c] with per_token=True (layers.py:210: a (B, dim_c, N) condition
     modulates every token with its own row; the Compressor's `pos_embedding: mlp`) — or None (plain LayerNorm block).
     x_bf16_out: optional bf16 [B*Nq, dim_out] buffer that receives a copy of the block's result (written by the fused MLP
-    kernel's own store pass, or by one cast on the unfused path)."""
+    kernel's own store pass, or by one cast on the unfused path).
+    next_P: packed holder of the plain-LayerNorm block that will run next on the same rows with a K/V source of its own (the
+    next decoder level): its LN1 + fc_q is then computed by THIS block's last kernel and `(x, q_next)` is returned — or
+    `(x, None)` when the shapes do not allow it; pass that `q_next` to the next call as `q_pre`."""
     C, Co, H = P["C"], P["Co"], P["H"]
     rps = 1 if per_token else Nq                                                    # rows that share one modulation row
     ln_kw = {}
@@ -86,7 +89,8 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
             qkv = ops.ln_linear(x, P["wqkv"], P["bqkv"], **aff, **ln_kw)
             q, kv, Nk = qkv[:, :Co], qkv[:, Co:], Nq
         else:
-            q = ops.ln_linear(x, P["wq"], P["bq"], **aff, **ln_kw)
+            # (q_pre: this block's LN1 + fc_q was already computed by the previous block's MLP kernel)
+            q = q_pre if (q_pre is not None and y_bf16 is not None) else ops.ln_linear(x, P["wq"], P["bq"], **aff, **ln_kw)
             if y_bf16 is None:                                                      # (not reached with the shipped shapes)
                 y_bf16, Nk = ops.layernorm_modulate(x, **({"w": P["n1"][0], "b": P["n1"][1]} if c is None else ln_kw)), Nq
             kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)
@@ -113,11 +117,18 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
                       gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=rps)
     if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0:
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
+        nxt = None
+        if next_P is not None and FUSED_ATTN and next_P["C"] == next_P["Co"] == Co and tuple(next_P["wq"].shape) == (Co, Co) \
+                and Co % 64 == 0 and next_P["n1"][0] is not None:
+            nxt = dict(w=next_P["wq"], bias=next_P["bq"], ln_w=next_P["n1"][0], ln_b=next_P["n1"][1])
         if c is not None:
-            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], shift=sh2, scale=sc2, gate=g2,
-                              mod_sample_stride=s2, rows_per_sample=rps, x_bf16_out=x_bf16_out)
+            r = ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], shift=sh2, scale=sc2, gate=g2,
+                                  mod_sample_stride=s2, rows_per_sample=rps, x_bf16_out=x_bf16_out, next_linear=nxt)
         else:
-            ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1], x_bf16_out=x_bf16_out)
+            r = ops.ln_mlp_resid_(x, P["wup"], P["bup"], P["wdn"], P["bdn"], ln_w=P["n2"][0], ln_b=P["n2"][1], x_bf16_out=x_bf16_out,
+                                  next_linear=nxt)
+        if next_P is not None:
+            return (x, r[1]) if nxt is not None else (x, None)
         return x
     if c is not None:
         h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
@@ -128,7 +139,7 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
                   gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=rps)
     if x_bf16_out is not None:
         x_bf16_out.copy_(ops.cast_pad_bf16(x, x_bf16_out.shape[1]))
-    return x
+    return (x, None) if next_P is not None else x
 
 
 def pack_final(fl):

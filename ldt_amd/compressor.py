@@ -346,19 +346,23 @@ class Compressor(nn.Module):
         km = keep_mask.to(prior.device)
         return torch.stack([prior[km[b]] for b in range(Bc)], 0).reshape(Bc * num_points, -1).contiguous()
 
-    def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None, o_bf16=None):
+    def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None, o_bf16=None, q_pre=None, next_P=None):
         """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j), c); c = label embedding in a class-conditional
         forward, None in `sample` (which never passes one, :263-264: the block then runs its plain-LayerNorm branch)."""
         zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
-        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c, x_bf16_out=o_bf16)
+        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c, x_bf16_out=o_bf16, q_pre=q_pre, next_P=next_P)
 
     def _decode_chunk(self, P, eps, N, keep_mask, seed_eps=None):
         Bc, T, _ = eps.shape
         o = self._initial_set(P, Bc, N, keep_mask, seed_eps)
         e2 = eps.view(Bc * T, -1)
+        q = None
         for j in range(self.n_layers):                                             # reversed(self.decoder), :263
             Pd = P["dec"][self.n_layers - 1 - j]
-            self._decoder_level(Pd, o, e2[:, self.z_dim * j: self.z_dim * (j + 1)], Bc, N, T)
+            # level j's last kernel also computes level j + 1's LN1 + fc_q on the rows it has just written (no condition here)
+            nxt = P["dec"][self.n_layers - 2 - j]["att1"] if j + 1 < self.n_layers else None
+            r = self._decoder_level(Pd, o, e2[:, self.z_dim * j: self.z_dim * (j + 1)], Bc, N, T, q_pre=q, next_P=nxt)
+            q = r[1] if nxt is not None else None
         return ops.sgemm(o, P["w_out"], P["b_out"]).view(Bc, N, 3)                 # Conv1d C -> 3, :266
 
     @staticmethod
@@ -434,6 +438,7 @@ class Compressor(nn.Module):
         o = self._initial_set(P, B, npts, keep_mask, seed_eps)
         all_eps = torch.empty((B * T, L * z), dtype=torch.float32, device=dev)
         stats = []
+        q_dec = None                                                                # next decoder level's query projection (fused)
         # bf16 image of o for the next level's att(x, o): written by the decoder block's last kernel, not by a pass of its own
         o_bf = torch.empty((B * npts, D), dtype=torch.bfloat16, device=dev) if (L > 1 and D % 64 == 0) else None
         for j in range(L):
@@ -448,7 +453,9 @@ class Compressor(nn.Module):
             nz = post_noise[j].to(dev, torch.float32).contiguous().view(B * T, z)
             ej = all_eps[:, z * j: z * (j + 1)]
             stats.append(ops.reparam(post, nz, ej, self.min_sigma, 10., want_stats))
-            self._decoder_level(Pd, o, ej, B, npts, T, c=l_emb, o_bf16=o_bf if j + 1 < L else None)
+            nxt = P["dec"][L - 2 - j]["att1"] if (j + 1 < L and l_emb is None) else None
+            r = self._decoder_level(Pd, o, ej, B, npts, T, c=l_emb, o_bf16=o_bf if j + 1 < L else None, q_pre=q_dec, next_P=nxt)
+            q_dec = r[1] if nxt is not None else None
         out = ops.sgemm(o, P["w_out"], P["b_out"]).view(B, npts, 3)
         res = {"set": self.postprocess(out), "all_eps": all_eps.view(B, T, L * z), "max": tok.max(),
                "posteriors": [(all_eps.view(B, T, L * z)[..., z * j: z * (j + 1)],) + tuple(

@@ -200,6 +200,20 @@ extern "C" int ldt_ln_mlp_resid(float* x, int64_t ldx, int64_t M, int32_t C, con
               BFM(x_bf16), ldxb};
     return ldt_ln_mlp_launch(&a, C, ST(stream));
 }
+extern "C" int ldt_ln_mlp_resid_next(float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
+                                     const float* shift, const float* scale, const float* gate, int64_t mod_sample_stride,
+                                     int32_t rows_per_sample, const uint16_t* w_up, const float* b_up, const uint16_t* w_dn,
+                                     const float* b_dn, uint16_t* x_bf16, int64_t ldxb,
+                                     const float* nx_ln_w, const float* nx_ln_b, const float* nx_shift, const float* nx_scale,
+                                     int64_t nx_mod_sample_stride, int32_t nx_rows_per_sample, const uint16_t* nx_w, const float* nx_bias,
+                                     int32_t nx_N, uint16_t* nx_out, int64_t nx_ldo, void* stream) {
+    LDT_REQUIRE(x && w_up && b_up && w_dn && b_dn && nx_w && nx_out, LDT_EARG, "ln_mlp_next: null pointer");
+    MlpArgs a{x, ldx, M, ln_w, ln_b, shift, scale, gate, mod_sample_stride, rows_per_sample, BF(w_up), b_up, BF(w_dn), b_dn,
+              BFM(x_bf16), ldxb,
+              LnLinArgs{nullptr, 0, M, nx_ln_w, nx_ln_b, nx_shift, nx_scale, nx_mod_sample_stride, nx_rows_per_sample, BF(nx_w), nx_bias,
+                        nx_N, BFM(nx_out), nx_ldo}};
+    return ldt_ln_mlp_launch(&a, C, ST(stream));
+}
 extern "C" int ldt_ln_linear(const float* x, int64_t ldx, int64_t M, int32_t C, const float* ln_w, const float* ln_b,
                              const float* shift, const float* scale, int64_t mod_sample_stride, int32_t rows_per_sample,
                              const uint16_t* w, const float* bias, int32_t N, uint16_t* out, int64_t ldo, void* stream) {

@@ -71,7 +71,7 @@ struct LnSrc {
     const float* x; long ldx; long M;
     const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
 };
-template <int C>
+template <int C, bool LOAD = true>    // LOAD = false: `xv` already holds the rows (the MLP kernel's freshly updated x)
 __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char* Hs, int wave, int lrow, int lq,
                                                  f32x4 (&xv)[C / 16][2], bf16x8 (&hf)[C / 32][2]) {
     using K = MlpCfg<C>;
@@ -80,9 +80,11 @@ __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char
     for (int rt = 0; rt < 2; ++rt) {
         long grow = row0 + rt * 16 + lrow;
         grow = grow < a.M ? grow : a.M - 1;                            // tail rows: clamp, never stored
-        const float* xr = a.x + grow * a.ldx + lq * 4;
+        if (LOAD) {
+            const float* xr = a.x + grow * a.ldx + lq * 4;
 #pragma unroll
-        for (int n = 0; n < C / 16; ++n) xv[n][rt] = *reinterpret_cast<const f32x4*>(xr + n * 16);
+            for (int n = 0; n < C / 16; ++n) xv[n][rt] = *reinterpret_cast<const f32x4*>(xr + n * 16);
+        }
         float s = 0.f;
 #pragma unroll
         for (int n = 0; n < C / 16; ++n) s += (xv[n][rt][0] + xv[n][rt][1]) + (xv[n][rt][2] + xv[n][rt][3]);
@@ -130,6 +132,60 @@ __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char
             const int hr = wave * 32 + rt * 16 + lrow;
             hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
         }
+}
+
+// out[rows][N] (bf16) = h . W^T + bias for the wave's 32 rows held as operand fragments `hf`; W streamed in chunks of 64 output
+// channels (chunk 0 already requested into W0 by the caller; double-buffered with the h image's LDS), the bf16 result chunk staged
+// through the wave's LDS rows so that whole 128-B row pieces are stored.
+template <int C>
+__device__ __forceinline__ void linear_chunks(const bf16_t* __restrict__ w, const float* __restrict__ bias, int N, bf16_t* __restrict__ out,
+                                              long ldo, long row0, long M, const bf16x8 (&hf)[C / 32][2], char* Hs, char* Us, char* W0,
+                                              int wave, int lane, int lrow, int lq) {
+    using K = MlpCfg<C>;
+    const int nch = N / 64;
+    for (int ch = 0; ch < nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* Wu = (ch & 1) ? Hs : W0;
+        if (ch + 1 < nch) stage_wup<C>(w, (ch + 1) * 64, (ch & 1) ? W0 : Hs, wave, lane);
+        f32x4 uacc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+            const int c = ks * 4 + lq;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int wr = t * 16 + lrow;
+                wf[t] = *reinterpret_cast<const bf16x8*>(Wu + wr * K::ROWB + ((c ^ swz<K::CB>(wr)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + ch * 64 + t * 16 + lq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 v = uacc[t][rt];
+                const bf16x4 pk = {(bf16_t)(v[0] + b4[0]), (bf16_t)(v[1] + b4[1]), (bf16_t)(v[2] + b4[2]), (bf16_t)(v[3] + b4[3])};
+                const int ur = wave * 32 + rt * 16 + lrow;
+                *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                               // 8 rows x 128 B per pass, 16 B per lane
+            const int r = it * 8 + (lane >> 3), cidx = lane & 7;
+            const int ur = wave * 32 + r;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((cidx ^ swz<8>(ur)) << 4));
+            if (row0 + r < M) *reinterpret_cast<bf16x8*>(out + (row0 + r) * ldo + ch * 64 + cidx * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // staging rows are rewritten by the next chunk
+    }
 }
 
 template <int C, bool GATED>
@@ -271,6 +327,16 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
             }
         }
     }
+
+    // ---- 4. (optional) the NEXT block's LayerNorm + first projection on the rows just produced (model/layers.py:218 / :225 of the
+    //         block that follows): its LN(x) . W^T is computed from the accumulators, so that block never reads x for it ----------
+    if (a.next.w) {
+        __syncthreads();                                               // every wave is done with both weight sets and its U rows
+        stage_wup<C>(a.next.w, 0, W0, wave, lane);
+        const LnSrc src{nullptr, 0, a.M, a.next.ln_w, a.next.ln_b, a.next.shift, a.next.scale, a.next.mod_sample_stride, a.next.rows_per_sample};
+        ln_rows_to_frags<C, false>(src, row0, Hs, wave, lrow, lq, oacc, hf);
+        linear_chunks<C>(a.next.w, a.next.bias, a.next.N, a.next.out, a.next.ldo, row0, a.M, hf, Hs, Us, W0, wave, lane, lrow, lq);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -289,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void ln_linear_kernel(const LnLinArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long row0 = (long)blockIdx.x * 128 + wave * 32;
     const int lrow = lane & 15, lq = lane >> 4;
-    const int nch = a.N / 64;
     stage_wup<C>(a.w, 0, W0, wave, lane);
     f32x4 xv[C / 16][2];
     bf16x8 hf[C / 32][2];
@@ -297,49 +362,7 @@ __global__ __launch_bounds__(256, 2) void ln_linear_kernel(const LnLinArgs a) {
         const LnSrc src{a.x, a.ldx, a.M, a.ln_w, a.ln_b, a.shift, a.scale, a.mod_sample_stride, a.rows_per_sample};
         ln_rows_to_frags<C>(src, row0, Hs, wave, lrow, lq, xv, hf);
     }
-    for (int ch = 0; ch < nch; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const char* Wu = (ch & 1) ? Hs : W0;
-        if (ch + 1 < nch) stage_wup<C>(a.w, (ch + 1) * 64, (ch & 1) ? W0 : Hs, wave, lane);
-        f32x4 uacc[4][2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
-#pragma unroll
-        for (int ks = 0; ks < C / 32; ++ks) {
-            const int c = ks * 4 + lq;
-            bf16x8 wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int wr = t * 16 + lrow;
-                wf[t] = *reinterpret_cast<const bf16x8*>(Wu + wr * K::ROWB + ((c ^ swz<K::CB>(wr)) << 4));
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch * 64 + t * 16 + lq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const f32x4 v = uacc[t][rt];
-                const bf16x4 pk = {(bf16_t)(v[0] + b4[0]), (bf16_t)(v[1] + b4[1]), (bf16_t)(v[2] + b4[2]), (bf16_t)(v[3] + b4[3])};
-                const int ur = wave * 32 + rt * 16 + lrow;
-                *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {                               // 8 rows x 128 B per pass, 16 B per lane
-            const int r = it * 8 + (lane >> 3), cidx = lane & 7;
-            const int ur = wave * 32 + r;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((cidx ^ swz<8>(ur)) << 4));
-            if (row0 + r < a.M) *reinterpret_cast<bf16x8*>(a.out + (row0 + r) * a.ldo + ch * 64 + cidx * 8) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // staging rows are rewritten by the next chunk
-    }
+    linear_chunks<C>(a.w, a.bias, a.N, a.out, a.ldo, row0, a.M, hf, Hs, Us, W0, wave, lane, lrow, lq);
 }
 
 template <int C>
@@ -371,6 +394,13 @@ int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st) {
                 (!a->ln_w || (ldt_aligned16(a->ln_w) && ldt_aligned16(a->ln_b))) &&
                 (!a->shift || (ldt_aligned16(a->shift) && ldt_aligned16(a->scale))) && (!a->gate || ldt_aligned16(a->gate)),
                 LDT_EALIGN, "ln_mlp: operands must be 16-byte aligned");
+    LDT_REQUIRE(!a->next.w || (a->next.N > 0 && a->next.N % 64 == 0 && a->next.out && a->next.ldo >= a->next.N && a->next.ldo % 8 == 0 &&
+                               ldt_aligned16(a->next.out) && ldt_aligned16(a->next.w) && (!a->next.bias || ldt_aligned16(a->next.bias)) &&
+                               (a->next.ln_w == nullptr) == (a->next.ln_b == nullptr) && (a->next.shift == nullptr) == (a->next.scale == nullptr) &&
+                               (!a->next.ln_w || (ldt_aligned16(a->next.ln_w) && ldt_aligned16(a->next.ln_b))) &&
+                               (!a->next.shift || (a->next.rows_per_sample > 0 && a->next.mod_sample_stride % 4 == 0 &&
+                                                   ldt_aligned16(a->next.shift) && ldt_aligned16(a->next.scale)))),
+                LDT_EARG, "ln_mlp: the follow-on LN + linear needs N %% 64 == 0, a 16-byte aligned bf16 output and paired, aligned LN vectors");
     LDT_REQUIRE(!a->x_bf16 || (a->ldxb >= C && a->ldxb % 4 == 0 && (reinterpret_cast<uintptr_t>(a->x_bf16) & 7) == 0), LDT_EALIGN,
                 "ln_mlp: bf16 mirror rows must be 8-byte aligned");
     if (a->gate) return C == 128 ? launch_mlp<128, true>(a, st) : launch_mlp<64, true>(a, st);

@@ -111,6 +111,12 @@ int ldt_reparam_launch(const float* post, const float* noise, float* out, long l
                        long rows, int z, float lo, float hi, hipStream_t s);
 int ldt_chamfer_launch(const float* a, const float* b, int B, int na, int nb, float* dl, float* dr, hipStream_t s);
 // fused LayerNorm + MLP + gated residual for narrow blocks (fused_mlp.hip)
+struct LnLinArgs {
+    const float* x; long ldx; long M;
+    const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
+    const bf16_t* w; const float* bias; int N;          // [N][C], [N] (nullable)
+    bf16_t* out; long ldo;
+};
 struct MlpArgs {
     float* x; long ldx; long M;
     const float* ln_w; const float* ln_b;              // affine LayerNorm (no-condition blocks) or null
@@ -120,15 +126,10 @@ struct MlpArgs {
     const bf16_t* w_up; const float* b_up;             // [4C][C], [4C]
     const bf16_t* w_dn; const float* b_dn;             // [C][4C], [C]
     bf16_t* x_bf16; long ldxb;                          // optional bf16 mirror of the updated x (the next block's K/V source) or null
+    LnLinArgs next;                                     // optional (next.w != null): LN + linear of the block that follows, on the new x (next.x unused)
 };
 int ldt_ln_mlp_launch(const MlpArgs* a, int C, hipStream_t st);
 // fused LayerNorm + linear (bf16 out) for narrow blocks (fused_mlp.hip)
-struct LnLinArgs {
-    const float* x; long ldx; long M;
-    const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
-    const bf16_t* w; const float* bias; int N;          // [N][C], [N] (nullable)
-    bf16_t* out; long ldo;
-};
 int ldt_ln_linear_launch(const LnLinArgs* a, int C, hipStream_t st);
 int ldt_chamfer_pairwise_launch(const float* x, const float* y, int S, int R, int n, int m, float* cd, hipStream_t st);
 int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, int m, int pairwise, float* out, hipStream_t st);

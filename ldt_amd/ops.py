@@ -332,9 +332,12 @@ def emd_approx(x, y, pairwise=False):
 
 
 def ln_mlp_resid_(x, w_up, b_up, w_dn, b_dn, ln_w=None, ln_b=None, shift=None, scale=None, gate=None,
-                  mod_sample_stride=0, rows_per_sample=0, x_bf16_out=None):
+                  mod_sample_stride=0, rows_per_sample=0, x_bf16_out=None, next_linear=None):
     """In place: x += gate * MLP(LN(x)[affine | modulated]) for C in {64, 128} channels (one fused kernel).
-    x_bf16_out: optional bf16 [M, >=C] row-major tensor that receives a copy of the updated x in the same pass."""
+    x_bf16_out: optional bf16 [M, >=C] row-major tensor that receives a copy of the updated x in the same pass.
+    next_linear: optional dict(w=bf16 [N, C], bias=fp32 [N] | None, ln_w=, ln_b= | shift=, scale=, mod_sample_stride=,
+    rows_per_sample=) — the following block's LayerNorm + first projection, computed on the updated rows by the same kernel;
+    then returns (x, out bf16 [M, N]) instead of x."""
     _need(x, torch.float32, "x"); _rowmajor(x, "x")
     M, Cc = x.shape
     if x_bf16_out is not None:
@@ -343,10 +346,24 @@ def ln_mlp_resid_(x, w_up, b_up, w_dn, b_dn, ln_w=None, ln_b=None, shift=None, s
             raise ValueError("ln_mlp_resid_: x_bf16_out must be [M, >=C]")
     if tuple(w_up.shape) != (4 * Cc, Cc) or tuple(w_dn.shape) != (Cc, 4 * Cc) or not (w_up.is_contiguous() and w_dn.is_contiguous()):
         raise ValueError("ln_mlp_resid_: weights must be dense bf16 [4C][C] and [C][4C]")
-    check(lib().ldt_ln_mlp_resid(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
-                                 rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), _p(x_bf16_out),
-                                 0 if x_bf16_out is None else x_bf16_out.stride(0), stream_ptr()), "ldt_ln_mlp_resid")
-    return x
+    ldxb = 0 if x_bf16_out is None else x_bf16_out.stride(0)
+    if next_linear is None:
+        check(lib().ldt_ln_mlp_resid(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
+                                     rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), _p(x_bf16_out), ldxb, stream_ptr()),
+              "ldt_ln_mlp_resid")
+        return x
+    nx = next_linear
+    wn = nx["w"]
+    _need(wn, torch.bfloat16, "next w")
+    if wn.shape[1] != Cc or not wn.is_contiguous():
+        raise ValueError("ln_mlp_resid_: next_linear w must be dense bf16 [N][C]")
+    out = torch.empty((M, wn.shape[0]), dtype=torch.bfloat16, device=x.device)
+    check(lib().ldt_ln_mlp_resid_next(_p(x), x.stride(0), M, Cc, _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(gate), mod_sample_stride,
+                                      rows_per_sample, _p(w_up), _p(b_up), _p(w_dn), _p(b_dn), _p(x_bf16_out), ldxb,
+                                      _p(nx.get("ln_w")), _p(nx.get("ln_b")), _p(nx.get("shift")), _p(nx.get("scale")),
+                                      nx.get("mod_sample_stride", 0), nx.get("rows_per_sample", 0), _p(wn), _p(nx.get("bias")),
+                                      wn.shape[0], _p(out), out.stride(0), stream_ptr()), "ldt_ln_mlp_resid_next")
+    return x, out
 
 
 def attention_oproj_resid_(q, k, v, B, H, Nq, Nk, head_dim, wo, bo, x, gate=None, gate_sample_stride=0):

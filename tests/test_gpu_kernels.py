@@ -343,6 +343,17 @@ def test_fused_ln_mlp_resid(C, M, mode):
     assert rel_mse(got_upd, upd) < 1e-4
     if mirror is not None:                      # the bf16 copy written in the same pass == a cast of the fp32 result, bit for bit
         assert torch.equal(mirror, xd.to(torch.bfloat16))
+    # the follow-on LayerNorm + linear of the next block, computed by the same launch on the rows it has just written,
+    # == ldt_ln_linear run on that result afterwards, bit for bit (plain and modulated next-LN)
+    wn = (torch.randn(2 * C, C, generator=g) / C ** 0.5).cuda().to(torch.bfloat16).contiguous()
+    bn = torch.randn(2 * C, generator=g).cuda()
+    nlw, nlb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    for nkw in (dict(ln_w=nlw, ln_b=nlb),) + ((dict(shift=md[:, :C], scale=md[:, C:2 * C], mod_sample_stride=3 * C, rows_per_sample=rps),) if mode == "mod" else ()):
+        x2 = x.cuda()
+        _, qn = ops.ln_mlp_resid_(x2, w_up.cuda().to(torch.bfloat16).contiguous(), b_up.cuda(), w_dn.cuda().to(torch.bfloat16).contiguous(),
+                                  b_dn.cuda(), next_linear=dict(w=wn, bias=bn, **nkw), **kw)
+        assert torch.equal(x2, xd)
+        assert torch.equal(qn, ops.ln_linear(xd, wn, bn, **nkw))
     with pytest.raises(Exception):
         ops.ln_mlp_resid_(torch.zeros(8, 96, device="cuda"), torch.zeros(384, 96, device="cuda", dtype=torch.bfloat16),
                           torch.zeros(384, device="cuda"), torch.zeros(96, 384, device="cuda", dtype=torch.bfloat16), torch.zeros(96, device="cuda"))
