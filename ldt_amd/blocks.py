@@ -53,13 +53,14 @@ def pack_block(blk):
     return P
 
 
-def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None, q_pre=None, next_P=None):
+def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None, q_pre=None, next_P=None, kv_pre=None):
     """x fp32 [B*Nq, C] updated IN PLACE (and returned) when dim_out == dim_in; a NEW [B*Nq, dim_out] tensor is returned
     for a U-Net down block.  y_bf16: raw K/V source [B*Nk, Ckv] (bf16) or None (self, modulated).
     c: fp32 [B, dim_c] condition (AdaLN) — or [B*Nq, dim_c] with per_token=True (layers.py:210: a (B, dim_c, N) condition
     modulates every token with its own row; the Compressor's `pos_embedding: mlp`) — or None (plain LayerNorm block).
     x_bf16_out: optional bf16 [B*Nq, dim_out] buffer that receives a copy of the block's result (written by the fused MLP
     kernel's own store pass, or by one cast on the unfused path).
+    kv_pre: bf16 [B*Nk, 2*dim_out] = fc_kv(y) computed by the caller (then y_bf16 is not needed: pass Nk).
     next_P: packed holder of the plain-LayerNorm block that will run next on the same rows with a K/V source of its own (the
     next decoder level): its LN1 + fc_q is then computed by THIS block's last kernel and `(x, q_next)` is returned — or
     `(x, None)` when the shapes do not allow it; pass that `q_next` to the next call as `q_pre`."""
@@ -85,24 +86,25 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
         # LN1 (+ modulate | affine) + fc_q [+ fc_kv on the same normalised input] in ONE kernel (csrc/fused_mlp.hip):
         # the normalised activations are never written
         aff = {} if c is not None else dict(ln_w=P["n1"][0], ln_b=P["n1"][1])
-        if y_bf16 is None and "wqkv" in P:
+        if y_bf16 is None and kv_pre is None and "wqkv" in P:
             qkv = ops.ln_linear(x, P["wqkv"], P["bqkv"], **aff, **ln_kw)
             q, kv, Nk = qkv[:, :Co], qkv[:, Co:], Nq
         else:
             # (q_pre: this block's LN1 + fc_q was already computed by the previous block's MLP kernel)
-            q = q_pre if (q_pre is not None and y_bf16 is not None) else ops.ln_linear(x, P["wq"], P["bq"], **aff, **ln_kw)
-            if y_bf16 is None:                                                      # (not reached with the shipped shapes)
+            ext = y_bf16 is not None or kv_pre is not None                           # K/V come from another tensor
+            q = q_pre if (q_pre is not None and ext) else ops.ln_linear(x, P["wq"], P["bq"], **aff, **ln_kw)
+            if not ext:                                                             # (not reached with the shipped shapes)
                 y_bf16, Nk = ops.layernorm_modulate(x, **({"w": P["n1"][0], "b": P["n1"][1]} if c is None else ln_kw)), Nq
-            kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)
+            kv = kv_pre if kv_pre is not None else ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)
     else:
         if c is not None:
             h = ops.layernorm_modulate(x, **ln_kw)
         else:
             h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
         q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
-        if y_bf16 is None:
+        if y_bf16 is None and kv_pre is None:
             y_bf16, Nk = h, Nq
-        kv = ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)                    # [B*Nk, 2Co]: K | V  (layers.py:189)
+        kv = kv_pre if kv_pre is not None else ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)   # [B*Nk, 2Co]: K | V  (layers.py:189)
     if C != Co:                                                                     # shortcut(x): Conv1d dim_in -> dim_out
         from ._lib import EPI_F32
         x = ops.gemm_bf16(ops.cast_pad_bf16(x, ops.pad64(C)), P["wsc"], P["bsc"], EPI_F32)

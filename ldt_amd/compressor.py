@@ -271,9 +271,12 @@ class Compressor(nn.Module):
         with torch.no_grad():
             P = {"dec": [], "enc": []}
             for d in self.decoder:
+                # DecoderBlock.forward (Network.py:80-83): att1's K/V source is ln(eps_j) and nothing else reads it, so
+                # fc_kv(ln(eps)) is ONE fp32 linear z_dim -> 2C: W = Wkv . Wln, b = Wkv . b_ln + b_kv
+                wkv, wln = f32(conv_w(d.att1.fc_kv)), f32(conv_w(d.ln))
                 P["dec"].append({
                     "att1": pack_block(d.att1), "att": pack_block(d.att),
-                    "w_ln": f32(conv_w(d.ln)), "b_ln": f32(d.ln.bias),
+                    "w_zkv": (wkv @ wln).contiguous(), "b_zkv": (wkv @ f32(d.ln.bias) + f32(d.att1.fc_kv.bias)).contiguous(),
                     "w_prior": f32(conv_w(d.prior[1])), "b_prior": f32(d.prior[1].bias)})
             for e in self.encoder:
                 P["enc"].append({"atts": [pack_block(a) for a in e.atts], "out": pack_final(e.conv_out)})
@@ -349,8 +352,8 @@ class Compressor(nn.Module):
     def _decoder_level(self, Pd, o, eps_j, Bc, N, T, c=None, o_bf16=None, q_pre=None, next_P=None):
         """DecoderBlock.forward (Network.py:80-83): o <- att1(o, ln(eps_j), c); c = label embedding in a class-conditional
         forward, None in `sample` (which never passes one, :263-264: the block then runs its plain-LayerNorm branch)."""
-        zb = ops.sgemm(eps_j, Pd["w_ln"], Pd["b_ln"], out_bf16=True)              # Conv1d z_dim -> C on T tokens
-        return residual_block(Pd["att1"], o, Bc, N, y_bf16=zb, Nk=T, c=c, x_bf16_out=o_bf16, q_pre=q_pre, next_P=next_P)
+        kv = ops.sgemm(eps_j, Pd["w_zkv"], Pd["b_zkv"], out_bf16=True)           # fc_kv(Conv1d z_dim -> C) on T tokens, composed
+        return residual_block(Pd["att1"], o, Bc, N, kv_pre=kv, Nk=T, c=c, x_bf16_out=o_bf16, q_pre=q_pre, next_P=next_P)
 
     def _decode_chunk(self, P, eps, N, keep_mask, seed_eps=None):
         Bc, T, _ = eps.shape
