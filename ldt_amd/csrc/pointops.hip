@@ -138,6 +138,60 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
             if (dist_out) dist_out[q * n + i] = d;
         } else key[j] = 0xFFFFFFFFu;
     }
+    int* o = out + q * (long)k;
+    // Fast path (k <= 64): the k-th smallest key cannot exceed tau = the k-th smallest of the 64 per-lane minima (those are k
+    // distinct points <= tau), so only points <= tau are candidates — a few more than k, unless many points tie or crowd below
+    // tau.  With <= 64 candidates they are compacted to one per lane (in index order) and the exact radix select runs on 64
+    // values: 32 + 32 + 32 ballots instead of 32 x PPL.  Same result, same output order as the full select below.
+    if (k <= 64) {
+        uint32_t m = key[0];
+#pragma unroll
+        for (int j = 1; j < PPL; ++j) m = min(m, key[j]);
+        uint32_t tau = 0;
+        int need1 = k;
+        for (int bit = 31; bit >= 0; --bit) {
+            const bool match = (bit == 31) || (((m ^ tau) >> (bit + 1)) == 0);
+            const int c0 = (int)__popcll(__ballot(match && !((m >> bit) & 1u)));
+            if (c0 < need1) { tau |= (1u << bit); need1 -= c0; }
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) cnt += (int)__popcll(__ballot(key[j] <= tau && lane + 64 * j < n));
+        if (cnt <= 64) {
+            __shared__ uint2 cand_s[4][64];
+            uint2* cand = cand_s[threadIdx.x >> 6];                     // wave-private: no workgroup barrier needed
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const bool sel = key[j] <= tau && lane + 64 * j < n;
+                const unsigned long long bal = __ballot(sel);
+                if (sel) cand[base + (int)__popcll(bal & lt)] = make_uint2(key[j], (uint32_t)(lane + 64 * j));
+                base += (int)__popcll(bal);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint2 mine = cand[lane];
+            const bool live = lane < cnt;
+            const uint32_t ck = live ? mine.x : 0xFFFFFFFFu;
+            uint32_t kth = 0;
+            int need2 = k;
+            for (int bit = 31; bit >= 0; --bit) {
+                const bool match = (bit == 31) || (((ck ^ kth) >> (bit + 1)) == 0);
+                const int c0 = (int)__popcll(__ballot(live && match && !((ck >> bit) & 1u)));
+                if (c0 < need2) { kth |= (1u << bit); need2 -= c0; }
+            }
+            const bool sel = live && ck < kth;
+            const unsigned long long bal = __ballot(sel);
+            if (sel) o[__popcll(bal & lt)] = (int)mine.y;
+            const int nlt = (int)__popcll(bal);
+            const bool eq = live && ck == kth;
+            const unsigned long long beq = __ballot(eq);
+            const int r = (int)__popcll(beq & lt);
+            if (eq && r < k - nlt) o[nlt + r] = (int)mine.y;
+            return;
+        }
+    }
     // radix select: the k-th smallest key
     uint32_t prefix = 0;
     int need = k;
@@ -154,7 +208,6 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         else { prefix |= (1u << bit); need -= c0; }
     }
     // emit: all keys < kth, then `need` keys == kth in index order
-    int* o = out + q * (long)k;
     int base = 0;
     int lt_total = 0;
 #pragma unroll

@@ -291,3 +291,23 @@ def test_fused_grouper_vs_oracle_and_chain(mods, B, n, S, k):
     # same bf16 operands and roundings, another summation order: equal up to a bf16 ulp on a few elements
     assert rel_mse(fused[1], chain[1]) < 1e-5
     assert float((fused[1] != chain[1]).float().mean()) < 0.25
+
+
+@pytest.mark.parametrize("n,S,k,levels", [(2048, 64, 16, 3), (1000, 16, 32, 2), (640, 9, 64, 5), (2048, 8, 16, 40)])
+def test_knn_ties_and_crowding(mods, n, S, k, levels):
+    """Points on a coarse lattice: masses of exactly equal distances.  The candidate fast path of the kNN select (points at or
+    below the k-th smallest per-lane minimum, compacted when there are <= 64) must hand over to the full radix select when
+    ties crowd below the threshold, and both must return k distinct neighbours whose sorted distances equal the reference's."""
+    ops, O = mods
+    g = torch.Generator().manual_seed(n + k)
+    p = (torch.randint(0, levels, (2, n, 3), generator=g).float() / levels) - 0.5
+    cen = p[:, :S].clone()
+    ref_d = O.square_distance(cen, p)
+    idx, dist = ops.knn(p.cuda(), cen.cuda(), k, return_dist=True)
+    idx = idx.cpu().long()
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    assert all(len(set(r.tolist())) == k for r in idx.reshape(-1, k))
+    got = torch.gather(dist.cpu(), -1, idx).sort(-1)[0]
+    want = dist.cpu().sort(-1)[0][..., :k]
+    assert torch.equal(got, want)                                            # exactly the k smallest distances, ties included
+    assert float((dist.cpu() - ref_d).abs().max()) < 2e-6
