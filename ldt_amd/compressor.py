@@ -228,7 +228,7 @@ class Compressor(nn.Module):
         if cfg.pre_group:                                               # Network.py:160-161 (created last, as upstream)
             self.pre_grouper = LocalGrouper(self.hidden_dim, True, normalize=cfg.cluster_norm)
         self._pack, self._pack_key = None, None
-        self.decode_chunk = 128          # samples per decode pass (activations ~7 MB/sample at 2048 points)
+        self.decode_chunk = 512          # samples per decode pass (activations ~7 MB/sample at 2048 points: 3.6 GB of the 288)
         # True: consume the CPU generator exactly as the reference does (B randperms per InitialSet call even when all rows
         # are kept; posterior noise drawn with CPU randn and copied over) so that seeded runs stay stream-aligned with it.
         # False (default): no idle randperms, posterior noise from the device-side Philox keyed by ONE CPU draw — the CPU

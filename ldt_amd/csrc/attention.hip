@@ -424,6 +424,139 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Resident form of the fused attention + output projection + residual (narrow blocks, Dh = 32) for cross-attention from many
+// queries to few keys — the Compressor's decoder levels: 2048 point queries x T <= 512 token keys per cloud.  The streaming kernel
+// above gives every 128-query block a workgroup of its own, and each of them re-reads the head's K/V (32 KB) and all of Wo (32 KB)
+// from L2: 64 KB of operands for 5 MFLOP, 4.2 GB of L2 traffic per launch at 1024 clouds next to 2.5 GB of HBM data.  Here one
+// workgroup owns a (cloud, head): K/V go to LDS once, each wave keeps its C/4 output channels of Wo as register fragments, and
+// the workgroup walks the head's query blocks (no barrier inside the attention; two per block around the 8 KB output stage).
+template <int H>   // heads: C = 32 H channels (2 or 4)
+__global__ __launch_bounds__(256, 4) void attn_oproj_resident_kernel(const AttnArgs a, int ntl) {
+    constexpr int DH = 32, KT = 64, ROWB = DH * 2, CH = ROWB / 16, NS = DH / 16, TILE = KT * ROWB;
+    constexpr int C = H * DH, R = 128 / H, NT = C / 64, RT = R / 16, rowb = C * 2;
+    extern __shared__ __attribute__((aligned(16))) char rsmem[];       // [K: ntl tiles][V: ntl tiles][O stage: R rows x C bf16 = 8 KB]
+    char* Ks = rsmem;
+    char* Vs = rsmem + ntl * TILE;
+    char* Ost = rsmem + 2 * ntl * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.x;
+    const int b = bh / H, head = bh % H;
+    const bf16_t* Qb = a.Q + (long)b * a.q_batch_stride + head * DH;
+    const bf16_t* Kb = a.K + (long)b * a.kv_batch_stride + head * DH;
+    const bf16_t* Vb = a.V + (long)b * a.kv_batch_stride + head * DH;
+    auto swzK = [](int row) { return (row >> 2) & 3; };
+    auto swzO = [](int row) { return C == 128 ? (row & 15) : ((row >> 1) & 7); };
+    {   // every key / value row of the head (rows past Nk repeat row Nk-1: their P is exactly 0)
+        constexpr int RPL = 256 / CH;
+        const int row0 = tid / CH, ch = tid % CH;
+        const int kofs = row0 * ROWB + ((ch ^ swzK(row0)) << 4), vofs = row0 * ROWB + (ch << 4);
+        const int npass = ntl * KT / RPL;
+        for (int base = 0; base < npass; base += 4) {
+            bf16x8 kreg[4], vreg[4];
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int row = row0 + (base + l) * RPL;
+                const int krow = row < a.Nk ? row : a.Nk - 1;
+                kreg[l] = *reinterpret_cast<const bf16x8*>(Kb + (long)krow * a.ldk + ch * 8);
+                vreg[l] = *reinterpret_cast<const bf16x8*>(Vb + (long)krow * a.ldv + ch * 8);
+            }
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                if (base + l < npass) {
+                    *reinterpret_cast<bf16x8*>(Ks + kofs + (base + l) * RPL * ROWB) = kreg[l];
+                    *reinterpret_cast<bf16x8*>(Vs + vofs + (base + l) * RPL * ROWB) = vreg[l];
+                }
+        }
+    }
+    // this wave's output channels of Wo (A operand of out^T = Wo . O'^T), kept for every query block
+    const int lrow = lane & 15, lq = lane >> 4, n0 = wave * (C / 4);
+    bf16x8 wf[NT][C / 32];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks)
+            wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.Wo + (long)(n0 + nt * 16 + lrow) * C + ks * 32 + lq * 8);
+    __syncthreads();
+
+    const float c = a.scale_log2e;
+    AttnLaneOffs<DH> lo;
+    lo.init(lane);
+    const int nqb = (a.Nq + 127) / 128;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int q0 = qb * 128 + wave * 32;
+        bf16x8 qf[NS];
+        {
+            int qrow = q0 + r;
+            qrow = qrow < a.Nq ? qrow : a.Nq - 1;                           // rows past the end: computed, never stored
+            const bf16_t* qp = Qb + (long)qrow * a.ldq + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        }
+        f32x16 oacc[1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[0][i] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int t = 0; t < ntl; ++t)
+            attn_tile<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        // the workgroup's 128 x Dh outputs = R whole rows of the (B*Nq, C) matrix the reference reinterprets the head-major buffer
+        // as (quirk Q1): staged as those rows (B operand of the projection)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int flat = (wave * 32 + r) * DH + 8 * g + 4 * hh;
+            const int orow = flat / C, ocol = flat % C;
+            const bf16x4 pk = {(bf16_t)(oacc[0][4 * g + 0] * inv), (bf16_t)(oacc[0][4 * g + 1] * inv),
+                               (bf16_t)(oacc[0][4 * g + 2] * inv), (bf16_t)(oacc[0][4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(Ost + orow * rowb + (((ocol >> 3) ^ swzO(orow)) << 4) + (ocol & 7) * 2) = pk;
+        }
+        __syncthreads();
+        f32x4 pacc[NT][RT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < RT; ++jj) pacc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+            bf16x8 of[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int orow = rt * 16 + lrow;
+                of[rt] = *reinterpret_cast<const bf16x8*>(Ost + orow * rowb + (((ks * 4 + lq) ^ swzO(orow)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) pacc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], of[rt], pacc[nt][rt], 0, 0, 0);
+        }
+        const int qb0 = qb * 128;
+        const int valid_rows = (min(128, a.Nq - qb0)) / H;                // Nq % H == 0 (checked by the launcher)
+        const long xrow0 = (long)b * a.Nq + ((long)head * a.Nq + qb0) / H;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int orow = rt * 16 + lrow, ch = n0 + nt * 16 + lq * 4;
+                if (orow >= valid_rows) continue;
+                float* xp = a.X + (xrow0 + orow) * a.ldx + ch;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + ch);
+                f32x4 xo = *reinterpret_cast<const f32x4*>(xp);
+                if (a.gate) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.gate + (long)b * a.gate_sample_stride + ch);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xo[jj] += g4[jj] * (pacc[nt][rt][jj] + b4[jj]);
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xo[jj] += pacc[nt][rt][jj] + b4[jj];
+                }
+                *reinterpret_cast<f32x4*>(xp) = xo;
+            }
+        __syncthreads();                                                    // the stage is rewritten by the next query block
+    }
+}
+
 template <int DH>
 static int launch_resident(const AttnArgs* a, hipStream_t s) {
     const int ntl = (a->Nk + 63) / 64;
@@ -444,6 +577,22 @@ int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s) {
                 LDT_EALIGN, "attention_oproj: operands must be 16-byte aligned");
     const long nqb = (a->Nq + 127) / 128, groups = ((long)a->B * a->H + 7) / 8;
     LDT_REQUIRE(groups * 8 * nqb < (1L << 31), LDT_ESHAPE, "attention_oproj: grid too large");
+    // several query blocks per head, few keys, a (cloud, head) pair per CU or more: K/V + Wo resident, one workgroup per pair
+    // (config C4, 1024 clouds: decode 16.2 -> 15.3 ms at 128 clouds per call, 16.0 -> 14.5 at 512; encode 34.8 -> 32.9 ms)
+    static const int res_env = getenv("LDT_ATTN_OPROJ_RESIDENT") ? atoi(getenv("LDT_ATTN_OPROJ_RESIDENT")) : -1;   // 0 / 1 force (tools/dbg)
+    const bool fits = a->Nk <= 512;
+    if (fits && (res_env == 1 || (res_env != 0 && nqb >= 2 && (long)a->B * a->H >= 256))) {
+        const int ntl = (a->Nk + 63) / 64;
+        const size_t lds = (size_t)2 * ntl * 64 * 64 + 8192;
+        if (a->H == 4) {
+            LDT_ENSURE_LDS(&attn_oproj_resident_kernel<4>, 81920, "attention_oproj");
+            hipLaunchKernelGGL(attn_oproj_resident_kernel<4>, dim3((unsigned)(a->B * a->H)), dim3(256), lds, s, *a, ntl);
+        } else {
+            LDT_ENSURE_LDS(&attn_oproj_resident_kernel<2>, 81920, "attention_oproj");
+            hipLaunchKernelGGL(attn_oproj_resident_kernel<2>, dim3((unsigned)(a->B * a->H)), dim3(256), lds, s, *a, ntl);
+        }
+        return ldt_check_launch("attn_oproj_resident");
+    }
     hipLaunchKernelGGL((attn_fwd_kernel<32, true>), dim3((unsigned)(groups * 8 * nqb)), dim3(256), 0, s, *a);
     return ldt_check_launch("attn_oproj");
 }

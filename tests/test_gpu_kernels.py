@@ -360,7 +360,10 @@ def test_fused_ln_mlp_resid(C, M, mode):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,gated", [(3, 4, 2048, 256, False), (2, 4, 256, 2048, True), (2, 2, 64, 8, False), (3, 2, 8, 64, True),
-                                              (2, 4, 200, 100, True)])
+                                              (2, 4, 200, 100, True),
+                                              # resident form (one workgroup per (cloud, head): B*H >= 256, >= 2 query blocks)
+                                              (64, 4, 256, 256, True), (128, 2, 130, 8, False),
+                                              (256, 4, 512, 256, False), (512, 2, 520, 40, True), (256, 4, 1000, 500, True)])
 def test_fused_attention_oproj_resid(B, H, Nq, Nk, gated):
     """x += gate * (Wo . Attn(q,k,v)' + bo) with the raw head-merge reinterpret (quirk Q1) in one kernel vs a plain fp32
     PyTorch reference of the same op (relative MSE of the update <= 1e-4), and vs the two-kernel path it replaces."""
