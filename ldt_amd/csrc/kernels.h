@@ -84,6 +84,7 @@ bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status);   // sg
 bool ldt_skinny_linear_try(const SgemmArgs* a, hipStream_t s, int* status);   // skinny_linear.hip
 
 int ldt_fps_launch(const float* xyz, int B, int n, int m, int skip_near_origin, int* idx, hipStream_t s);
+int ldt_fps_wave_launch(const float* xyz, int B, int n, int m, int skip_near_origin, int* idx, hipStream_t s);   // fps_wave.hip
 int ldt_knn_launch(const float* xyz, const float* centers, int B, int n, int S, int k, int* out, float* dist_out, hipStream_t s);
 int ldt_group_launch(const float* feat, const float* xyz, const int* fps_idx, const int* knn_idx, const float* alpha,
                      const float* beta, double* stats, int B, int n, int S, int k, int D, bf16_t* U, int ldu,

@@ -3,6 +3,8 @@
 // posterior draw.  Integer/index work is exact; floating point follows the operation order stated per kernel.
 // Reference: model/Compressor/layers.py:65-112 (square_distance / knn_point / cluster), :288-319
 // (LocalGrouper.forward), model/functional/src/sampling/sampling.cu:86-167 (FPS twin), Network.py:26-29,76.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define TRY_LAUNCH(what) do { const int _rc = ldt_check_launch(what); if (_rc != LDT_OK) return _rc; } while (0)
@@ -94,6 +96,11 @@ __global__ __launch_bounds__(512) void fps_kernel(const float* __restrict__ xyz,
 int ldt_fps_launch(const float* xyz, int B, int n, int m, int skip_near_origin, int* idx, hipStream_t s) {
     LDT_REQUIRE(B > 0 && n > 0 && m > 0 && m <= n, LDT_ESHAPE, "fps: B=%d n=%d m=%d", B, n, m);
     LDT_REQUIRE(n <= 512 * 16, LDT_ESHAPE, "fps: n=%d > 8192 points per cloud not built", n);
+    static const int wave_env = getenv("LDT_FPS_WAVE") ? atoi(getenv("LDT_FPS_WAVE")) : -1;   // 0 / 1 force (tools/dbg)
+    // many clouds: one wave per cloud (all CUs busy from 1024 clouds up; a lone cloud is faster on 512 threads)
+    if (n <= 64 * 32 && (wave_env == 1 || (wave_env != 0 && B >= 512))) {
+        return ldt_fps_wave_launch(xyz, B, n, m, skip_near_origin, idx, s);
+    }
     if (n <= 512 * 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(B), dim3(512), 0, s, xyz, n, m, skip_near_origin, idx);
     else hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(512), 0, s, xyz, n, m, skip_near_origin, idx);
     return ldt_check_launch("fps");

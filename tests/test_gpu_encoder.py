@@ -311,3 +311,23 @@ def test_knn_ties_and_crowding(mods, n, S, k, levels):
     want = dist.cpu().sort(-1)[0][..., :k]
     assert torch.equal(got, want)                                            # exactly the k smallest distances, ties included
     assert float((dist.cpu() - ref_d).abs().max()) < 2e-6
+
+
+def test_fps_many_clouds_wave_form(mods):
+    """From 512 clouds per call FPS runs one wave per cloud (fps_wave.hip) instead of one 512-thread workgroup: same index sequences
+    as the workgroup form (run here on sub-batches), as the oracle on a subset, with ragged point counts, planted ties and both
+    settings of skip_near_origin."""
+    ops, O = mods
+    g = torch.Generator().manual_seed(11)
+    for n, m in ((2048, 40), (700, 33), (64, 64)):
+        p = torch.randn(520, n, 3, generator=g) * 0.5
+        p[:, 5] = p[:, n - 3]                                   # exact duplicates: ties between far-apart indices
+        if n > 600:
+            p[:, 513] = p[:, 2]
+        p[:, 7:40:3] *= 0.01                                    # points inside the 1e-3 ball
+        pd = p.cuda()
+        for skip in (False, True):
+            wave = ops.fps(pd, m, skip_near_origin=skip)
+            wg = torch.cat([ops.fps(pd[i:i + 130], m, skip_near_origin=skip) for i in range(0, 520, 130)])
+            assert torch.equal(wave, wg)
+            assert torch.equal(wave[:6].cpu().long(), O.fps(p[:6], m, skip_near_origin=skip))

@@ -7,7 +7,8 @@ REV=${1:-HEAD}
 rm -rf /tmp/head_src && mkdir -p /tmp/head_src/ldt_amd /tmp/head_src/include tools/dbg/lib
 git archive "$REV" ldt_amd/csrc include | tar -x -C /tmp/head_src
 for f in /tmp/head_src/ldt_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f -o /tmp/head_src/$(basename ${f%.hip}).o &
+  extra=""; case "$(basename $f)" in fps_wave.hip) extra="-fno-slp-vectorize" ;; esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c $f -o /tmp/head_src/$(basename ${f%.hip}).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/lib/libldt_HEAD.so /tmp/head_src/*.o

@@ -4,7 +4,8 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p tools/dbg/lib /tmp/var_$1
 for f in ldt_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c $f -o /tmp/var_$1/$(basename ${f%.hip}).o &
+  extra=""; case "$(basename $f)" in fps_wave.hip) extra="-fno-slp-vectorize" ;; esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 $extra -c $f -o /tmp/var_$1/$(basename ${f%.hip}).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dbg/lib/libldt_$1.so /tmp/var_$1/*.o
