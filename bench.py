@@ -310,7 +310,19 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
     with torch.no_grad():
         noise = [torch.randn(nb, T, cc.z_dim) for _ in range(L)]
         t0 = time.time(); r = O.compressor_encode(sd_c, cc, pts_h[:nb], noise); t_ce = time.time() - t0
-        t0 = time.time(); O.compressor_decode(sd_c, cc, r["all_eps"]); t_cd = time.time() - t0
+        t0 = time.time(); dec_ref = O.compressor_decode(sd_c, cc, r["all_eps"]); t_cd = time.time() - t0
+        # parity at full size, through the big-batch kernels: the whole batch is encoded / decoded again with the oracle's clouds, posterior
+        # noise and latents in its first `nb` slots, and those slots are compared (relative MSE; FPS indices exactly)
+        rel = lambda a, b: float(((a.double() - b.double()) ** 2).sum() / (b.double() ** 2).sum())
+        gn = torch.Generator().manual_seed(5)
+        full_noise = [torch.cat([n, torch.randn(batch - nb, T, cc.z_dim, generator=gn)]).cuda() for n in noise]
+        og = comp(pts, post_noise=full_noise)
+        eps_in = eps.clone(); eps_in[:nb] = r["all_eps"].cuda()
+        dg = comp.sample((batch, 2048), given_eps=eps_in)
+        par = {"clouds": nb, "of_batch": batch, "fps_idx_equal": bool(torch.equal(og["fps_idx"][:nb].cpu().long(), r["fps_idx"].long())),
+               "encode_all_eps_rel_mse": rel(og["all_eps"][:nb].cpu(), r["all_eps"]), "encode_set_rel_mse": rel(og["set"][:nb].cpu(), r["set"]),
+               "decode_rel_mse": rel(dg[:nb].cpu(), dec_ref), "tol": {"all_eps": 1e-4, "set": 1e-4, "decode": 1e-4}}
+        par["pass"] = bool(par["fps_idx_equal"] and par["encode_all_eps_rel_mse"] < 1e-4 and par["encode_set_rel_mse"] < 1e-4 and par["decode_rel_mse"] < 1e-4)
 
     def hb(bytes_, t):
         gbs = bytes_ / t / 1e9
@@ -326,6 +338,7 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
                                            "clouds_per_s": round(unfused_clouds_s, 1), "bytes_per_cloud": unfused_bytes,
                                            "measured_over_bound": round(batch / t_dec / unfused_clouds_s, 3)},
             "cross_attn_q2048_kvT": hb(b1, t1), "cross_attn_qT_kv2048": hb((2 * Bm * T * d + 2 * Bm * 2048 * d) * 2.0, t2),
+            "parity": par,
             "cpu_baseline": {"encode_clouds_per_s": round(nb / t_ce, 3), "decode_clouds_per_s": round(nb / t_cd, 3), "cores": host_cores(),
                              "kind": "port", "sample": "oracle compressor_encode / compressor_decode on %d of the %d clouds" % (nb, batch)}}
 

@@ -97,3 +97,38 @@ def test_c1_exact_free_running(full):
     with torch.no_grad():
         ref_dec = O.compressor_decode(full["sd_c"], cfg.compressor, zl)
     assert rel_mse(tr.compressor.sample((B, cfg.data.tr_max_sample_points), given_eps=zl.cuda()).cpu(), ref_dec) < 1e-4
+
+
+@pytest.mark.parametrize("tokens", [256, 32])
+def test_compressor_fullsize_big_batch_vs_oracle(tokens):
+    """BASELINE configs[3] shapes through the big-batch kernels (512 clouds per call: one-wave FPS, kNN candidate select, one-kernel
+    grouper with 16 / 128 neighbours, resident attention + out-projection, next-level q in the MLP kernel, streaming 3 <-> C convs):
+    the first 4 clouds of the batch carry the oracle's clouds, posterior noise and latents and are compared with its fp32 results —
+    FPS indices exactly, latents / reconstruction / decode by relative MSE (bf16 operands: <= 1e-4)."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    torch.set_num_threads(host_cores())
+    cfg = ldt_amd.airplane_config(latent_tokens=tokens)
+    cc = cfg.compressor
+    torch.manual_seed(3)
+    comp = ldt_amd.Compressor(cc)
+    comp.init()
+    sd = {k: v.detach().float().clone() for k, v in comp.state_dict().items()}
+    comp = comp.cuda()
+    B, nb = 512, 4
+    g = torch.Generator().manual_seed(tokens)
+    pts = torch.randn(B, 2048, 3, generator=g)
+    pts = pts - pts.mean(1, keepdim=True)
+    pts = pts / pts.norm(dim=-1).amax(1)[:, None, None]
+    noise = [torch.randn(B, tokens, cc.z_dim, generator=g) for _ in range(cc.n_layers)]
+    with torch.no_grad():
+        ref = O.compressor_encode(sd, cc, pts[:nb], [n[:nb] for n in noise])
+        ref_dec = O.compressor_decode(sd, cc, ref["all_eps"])
+    out = comp(pts.cuda(), post_noise=[n.cuda() for n in noise])
+    assert torch.equal(out["fps_idx"][:nb].cpu().long(), ref["fps_idx"].long())
+    assert rel_mse(out["all_eps"][:nb].cpu(), ref["all_eps"]) < 1e-4
+    assert rel_mse(out["set"][:nb].cpu(), ref["set"]) < 1e-4
+    eps_in = out["all_eps"].clone()
+    eps_in[:nb] = ref["all_eps"].cuda()
+    dec = comp.sample((B, 2048), given_eps=eps_in)
+    assert rel_mse(dec[:nb].cpu(), ref_dec) < 1e-4
