@@ -1,10 +1,10 @@
 // LocalGrouper rows + PreExtraction + neighbour max in ONE kernel (Compressor/layers.py:288-319 grouping and normalisation,
 // :115-160 PreExtraction = Conv+BN+ReLU, residual [Conv+BN+ReLU, Conv] + ReLU, :186 adaptive_max_pool1d over the k neighbours).
 //
-// The unfused chain writes the grouped rows U [B*S*k][2D+3 -> 320] bf16 (5.4 GB at B = 1024, S = 256, k = 32, D = 128), then
-// three [B*S*k][128] bf16 activations and reads them all back: ~26 GB of HBM traffic for 134 MB of result.  Here one wave
-// owns one group at a time and walks its neighbour rows 32 at a time — 32 rows ARE the 32 columns of a 32x32 MFMA tile
-// (k = 32 m: m tiles per group with a running max; k = 16 or 8: 2 or 4 whole groups share a tile):
+// The unfused chain writes the grouped rows U [B*S*k][2D+3 -> 320] bf16 (2.7 GB at B = 1024, S*k = 4096 neighbour rows per cloud,
+// D = 128), then three [B*S*k][128] bf16 activations and reads them all back: ~13 GB of HBM traffic for 134 MB of result.  Here a
+// wave's work item is a tile of 32 neighbour rows — 32 rows ARE the 32 columns of a 32x32 MFMA tile (k = 32 m: m tiles per group,
+// each by whichever wave comes to it, combined by atomicMax; k = 16 or 8: 2 or 4 whole groups share a tile):
 //
 //   layer 1  D1[c][j] = W1[c][:] . U[j][:]     weights = A operand (from LDS), U^T = B operand built in registers from the
 //                                              gathered feature rows (lane j gathers the 8 channels its k-slot needs),
