@@ -446,7 +446,7 @@ class Compressor(nn.Module):
         o_bf = torch.empty((B * npts, D), dtype=torch.bfloat16, device=dev) if (L > 1 and D % 64 == 0) else None
         for j in range(L):
             Pd = P["dec"][L - 1 - j]
-            xj = enc_out[-j - 1].clone()
+            xj = enc_out[-j - 1]                                                    # (each stage output is consumed once: updated in place)
             if j == 0:
                 y, nk = ops.cast_pad_bf16(xj, ops.pad64(D)), T                       # compute_posterior(x, None): att(x, x)
             else:                                                                   # att(x, o): K/V = 2048 decoded points
