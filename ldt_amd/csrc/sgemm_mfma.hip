@@ -8,14 +8,14 @@
 // operands come from LDS once per 32x32 block instead of once per 4x4 register tile.
 //
 // Structure: 256 threads = 4 waves; WG tile TM x TN (128x128: waves 2x2 of 64x64; 32x256: waves 1x4 of 32x64 for the skinny
-// per-step conditional AdaLN, M = batch), BK = 16, operands staged global -> registers -> LDS ([row][k], row stride 20
-// floats: conflict-free 16-B reads), double-buffered in registers (the next k-slab's global loads are in flight during the
+// per-step conditional AdaLN, M = batch), k-slabs of BK = 16 (32 for the skinny tile), operands staged global -> registers -> LDS
+// ([row][k], row stride BK + 4 floats: conflict-free 16-B reads), double-buffered in registers (the next k-slab's global loads are in flight during the
 // MFMAs).  Per 8 k's a lane reads ONE 16-B chunk per 32-row block: lanes 0-31 hold k 0..3, lanes 32-63 k 4..7 of that slab —
 // the MFMA pairs (k, k+4) instead of (k, k+1), the same permutation on both operands.
 #include "kernels.h"
 
-#define SG_BK 16
-#define SG_LD 20     /* floats per staged row: 16 + 4 pad */
+// k-slab depth BK (floats per staged row: BK + 4 pad -> conflict-free 16-B reads): 16 for the square tile; 32 for the skinny one, whose
+// launch is pure weight streaming with ONE slab in flight per workgroup — a deeper slab is more bytes per memory latency
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
@@ -28,11 +28,12 @@ __device__ __forceinline__ float sg_act(float v, int act) {
     }
 }
 
-template <int TM, int TN, int WGM, int WGN>    // WG tile, wave grid (WGM x WGN = 4 waves)
+template <int TM, int TN, int WGM, int WGN, int SG_BK = 16>    // WG tile, wave grid (WGM x WGN = 4 waves), k-slab depth
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const SgemmArgs a) {
+    constexpr int SG_LD = SG_BK + 4, CPR = SG_BK / 4;                  // floats per staged row, 16-B chunks per slab row
     constexpr int WM = TM / WGM, WN = TN / WGN;       // per-wave tile
     constexpr int BM = WM / 32, BN = WN / 32;          // 32x32 MFMA blocks per wave
-    constexpr int CA = (TM * 4 + 255) / 256, CB = (TN * 4 + 255) / 256;   // 16-B chunks per thread and slab (a slab row = 4 chunks)
+    constexpr int CA = (TM * CPR + 255) / 256, CB = (TN * CPR + 255) / 256;   // 16-B chunks per thread and slab
     static_assert(WGM * WGN == 4 && BM >= 1 && BN >= 1, "tile shape");
     __shared__ __attribute__((aligned(16))) float As[TM * SG_LD];
     __shared__ __attribute__((aligned(16))) float Bs[TN * SG_LD];
@@ -49,37 +50,37 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const SgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging map: chunk c of a slab = (row = c >> 2, k-chunk = c & 3); thread t takes chunks t, t + 256, ...
+    // staging map: chunk c of a slab = (row = c / CPR, k-chunk = c % CPR); thread t takes chunks t, t + 256, ...
     f32x4 ra[CA], rb[CB];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int c = 0; c < CA; ++c) {
-            const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
+            const int ch = tid + c * 256, row = ch / CPR, kc = (ch % CPR) * 4;
             const int m = m0 + row;
-            ra[c] = (ch < TM * 4 && m < a.M && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[c] = (ch < TM * CPR && m < a.M && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (long)m * a.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-            const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
+            const int ch = tid + c * 256, row = ch / CPR, kc = (ch % CPR) * 4;
             const int n = n0 + row;
-            rb[c] = (ch < TN * 4 && n < a.N && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.B + (long)n * a.ldb + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[c] = (ch < TN * CPR && n < a.N && k0 + kc < a.K) ? *reinterpret_cast<const f32x4*>(a.B + (long)n * a.ldb + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int c = 0; c < CA; ++c) {
-            const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
+            const int ch = tid + c * 256, row = ch / CPR, kc = (ch % CPR) * 4;
             f32x4 v = ra[c];
             if (a.act_in) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = sg_act(v[j], a.act_in);
             }
-            if (ch < TM * 4) *reinterpret_cast<f32x4*>(&As[row * SG_LD + kc]) = v;
+            if (ch < TM * CPR) *reinterpret_cast<f32x4*>(&As[row * SG_LD + kc]) = v;
         }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-            const int ch = tid + c * 256, row = ch >> 2, kc = (ch & 3) * 4;
-            if (ch < TN * 4) *reinterpret_cast<f32x4*>(&Bs[row * SG_LD + kc]) = rb[c];
+            const int ch = tid + c * 256, row = ch / CPR, kc = (ch % CPR) * 4;
+            if (ch < TN * CPR) *reinterpret_cast<f32x4*>(&Bs[row * SG_LD + kc]) = rb[c];
         }
     };
 
@@ -133,7 +134,7 @@ bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status) {
     if ((long)a->M * a->N < 64 * 64) return false;       // tiny problems: launch-bound either way, keep the simple kernel
     if (a->M <= 48) {                                     // skinny: per-step per-sample AdaLN rows (M = batch), weight streaming
         dim3 grid((a->N + 255) / 256, (a->M + 31) / 32);
-        hipLaunchKernelGGL((sgemm_mfma_kernel<32, 256, 1, 4>), grid, dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((sgemm_mfma_kernel<32, 256, 1, 4, 32>), grid, dim3(256), 0, s, *a);   // (215 -> 190 us at M = 32, N = 149,504; 128 x 64 slabs: equal)
     } else {
         dim3 grid((a->N + 127) / 128, (a->M + 127) / 128);
         if (grid.y >= 65536) return false;
