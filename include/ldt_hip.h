@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 11
+#define LDT_ABI_VERSION 12
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -151,6 +151,17 @@ int ldt_langevin_coef(const float* sums, int32_t n_total, float snr, float std_t
 int ldt_pndm_transfer(const float* x, const float* et, float d, float p, float q, float* out, int64_t n, void* stream);
 int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float* a3, float c0, float c1, float c2, float c3,
                  float s, float* out, int64_t n, void* stream);
+
+/* ---- small fp32 element-wise helpers of the host orchestration ---------------------------------------------
+ * ldt_vpsde_score: out[b,:] = -params[b,:] / sqrt(var(t[b])), var(t) = 1 - (1 - sigma2_0) exp(-beta0 t - (beta1-beta0) t^2 / 2)
+ *   in fp32 — the `score` half of Trainer.score_fn's return value (trainer/Latent_SDE_Trainer.py:57-61 with
+ *   DiffusionVPSDE.var, diffusion/diffusion_continuous.py:649-651).
+ * ldt_add_f32: out = a + b (c = t_emb + label / image-condition embedding, model/scorenet/score.py:135).
+ * ldt_widen_bf16: fp32 copy of a packed bf16 panel (exact). */
+int ldt_vpsde_score(const float* params, const float* t, float beta0, float beta1, float sigma2_0, float* out, int32_t B,
+                    int64_t per_sample, void* stream);
+int ldt_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
 
 /* ---- Compressor encoder front end (model/Compressor/layers.py:65-112, 288-319; Network.py:26-29,76,86-107) ----
  * Clouds are fp32 [B][n][3]; index outputs are int32.

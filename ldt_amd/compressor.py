@@ -276,7 +276,8 @@ class Compressor(nn.Module):
                 wkv, wln = f32(conv_w(d.att1.fc_kv)), f32(conv_w(d.ln))
                 P["dec"].append({
                     "att1": pack_block(d.att1), "att": pack_block(d.att),
-                    "w_zkv": (wkv @ wln).contiguous(), "b_zkv": (wkv @ f32(d.ln.bias) + f32(d.att1.fc_kv.bias)).contiguous(),
+                    "w_zkv": ops.sgemm(wkv, wln.t().contiguous()),
+                    "b_zkv": ops.sgemm(f32(d.ln.bias).view(1, -1), wkv, f32(d.att1.fc_kv.bias)).view(-1),
                     "w_prior": f32(conv_w(d.prior[1])), "b_prior": f32(d.prior[1].bias)})
             for e in self.encoder:
                 P["enc"].append({"atts": [pack_block(a) for a in e.atts], "out": pack_final(e.conv_out)})

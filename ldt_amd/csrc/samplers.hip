@@ -124,3 +124,66 @@ extern "C" int ldt_lincomb4(const float* a0, const float* a1, const float* a2, c
     hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
     return ldt_check_launch("lincomb4");
 }
+
+// ------------------------------------------------------------------------------------------------
+// score = -params / sqrt(var(t)) of Trainer.score_fn (trainer/Latent_SDE_Trainer.py:57-61) with var(t) of the VP-SDE
+// (diffusion/diffusion_continuous.py:649-651) evaluated per sample in fp32 in the reference's op order:
+//   var = 1 - (1 - sigma2_0) * exp(-beta0 t - 0.5 (beta1 - beta0) t t)
+__global__ __launch_bounds__(256) void vpsde_score_kernel(const float* __restrict__ params, const float* __restrict__ t, float beta0, float beta1,
+                                                          float sigma2_0, float* __restrict__ out, long per4) {
+    const float tb = t[blockIdx.y];
+    float sd;
+    {
+#pragma clang fp contract(off)
+        const float a = -beta0 * tb;
+        const float b = (0.5f * (beta1 - beta0)) * tb * tb;
+        const float var = 1.0f - (1.0f - sigma2_0) * expf(a - b);
+        sd = sqrtf(var);
+    }
+    const float* src = params + (long)blockIdx.y * per4 * 4;
+    float* dst = out + (long)blockIdx.y * per4 * 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = -v[j] / sd;
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+    }
+}
+extern "C" int ldt_vpsde_score(const float* params, const float* t, float beta0, float beta1, float sigma2_0, float* out, int32_t B,
+                               int64_t per_sample, void* stream) {
+    LDT_REQUIRE(params && t && out, LDT_EARG, "vpsde_score: null pointer");
+    LDT_REQUIRE(B > 0 && B <= 65535 && per_sample > 0 && per_sample % 4 == 0 && ldt_aligned16(params) && ldt_aligned16(out), LDT_ESHAPE,
+                "vpsde_score: B=%d in [1, 65535], per_sample=%ld a multiple of 4, 16-byte aligned buffers", B, (long)per_sample);
+    long bx = (per_sample / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(vpsde_score_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params, t,
+                       beta0, beta1, sigma2_0, out, (long)(per_sample / 4));
+    return ldt_check_launch("vpsde_score");
+}
+
+// out = a + b (fp32; c = t_emb + label / image-condition embedding, model/scorenet/score.py:135).  out may alias a or b.
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+extern "C" int ldt_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    LDT_REQUIRE(a && b && out && n > 0, LDT_EARG, "add_f32: bad argument");
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b, out, (long)n);
+    return ldt_check_launch("add_f32");
+}
+
+// bf16 -> fp32 widening of a packed weight panel (exact), for the fp32 table builds that must see the SAME rounded weights
+// the MFMAs multiply by (Score.fold_table).
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (float)src[i];
+}
+extern "C" int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream) {
+    LDT_REQUIRE(src && dst && n > 0, LDT_EARG, "widen_bf16: bad argument");
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(src), dst, (long)n);
+    return ldt_check_launch("widen_bf16");
+}

@@ -170,6 +170,38 @@ def sampler_step(x, params, coef, step, mode=0, noise=None, noise_step_stride=0,
     return x_out
 
 
+def vpsde_score(params, t, beta0, beta1, sigma2_0):
+    """-params / sqrt(var(t)) per sample (Trainer.score_fn, Latent_SDE_Trainer.py:57-61): params fp32 [B, ...], t fp32 [B]."""
+    _need(params, torch.float32, "params"); _need(t, torch.float32, "t")
+    params, t = params.contiguous(), t.contiguous()
+    out = torch.empty_like(params)
+    B = params.shape[0]
+    check(lib().ldt_vpsde_score(_p(params), _p(t), float(beta0), float(beta1), float(sigma2_0), _p(out), B, params.numel() // B,
+                                stream_ptr()), "ldt_vpsde_score")
+    return out
+
+
+def add_f32(a, b, out=None):
+    """a + b, fp32, same shape."""
+    _need(a, torch.float32, "a"); _need(b, torch.float32, "b")
+    if a.shape != b.shape:
+        raise ValueError("add_f32: shapes differ %s %s" % (tuple(a.shape), tuple(b.shape)))
+    a, b = a.contiguous(), b.contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().ldt_add_f32(_p(a), _p(b), _p(out), a.numel(), stream_ptr()), "ldt_add_f32")
+    return out
+
+
+def widen_bf16(w):
+    """bf16 -> fp32 copy (exact)."""
+    _need(w, torch.bfloat16, "w")
+    w = w.contiguous()
+    out = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+    check(lib().ldt_widen_bf16(_p(w), _p(out), w.numel(), stream_ptr()), "ldt_widen_bf16")
+    return out
+
+
 def philox_normal(shape, device, seed, step=0, elem_offset=0):
     out = torch.empty(shape, dtype=torch.float32, device=device)
     check(lib().ldt_philox_normal(_p(out), out.numel(), elem_offset, step, seed, stream_ptr()), "ldt_philox_normal")

@@ -246,7 +246,7 @@ class Score(nn.Module):
         h = ops.sgemm(e, te[0].weight, te[0].bias, act_out=ACT_SILU)
         c = ops.sgemm(h, te[2].weight, te[2].bias)
         if extra_c is not None:
-            c = c + extra_c
+            c = ops.add_f32(c, extra_c.expand_as(c))
         D = self.hidden_size
         mod = torch.empty((t.numel(), self.n_mod), dtype=torch.float32, device=t.device)
         for l, blk in enumerate(self.Transformer):
@@ -279,13 +279,14 @@ class Score(nn.Module):
         n = mod.shape[0]
         fb = 6 * D + 2 * F
         fold = torch.empty((n, self.num_blocks * fb), dtype=torch.float32, device=mod.device)
+        ones = torch.ones((1, D), dtype=torch.float32, device=mod.device)
         for l in range(self.num_blocks):
             m0, f0 = l * 6 * D, l * fb
             for (w, b, sh, sc, off) in ((P["w_qkv"][l], P["b_qkv"][l], m0, m0 + D, f0),
                                         (P["w_up"][l], P["b_up"][l], m0 + 3 * D, m0 + 4 * D, f0 + 6 * D)):
-                wf = w.float()
+                wf = ops.widen_bf16(w)
                 N = wf.shape[0]
-                ops.sgemm(mod[:, sc:sc + D], wf, wf.sum(1), out=fold[:, off:off + N])               # S
+                ops.sgemm(mod[:, sc:sc + D], wf, ops.sgemm(ones, wf).view(-1), out=fold[:, off:off + N])   # S (row sums as the bias)
                 ops.sgemm(mod[:, sh:sh + D], wf, b, out=fold[:, off + N:off + 2 * N])               # C
         return fold
 
@@ -358,9 +359,9 @@ class Score(nn.Module):
         P = self.packed()
         c = self.time_embedding(t.to(x).float())
         if label is not None:
-            c = c + self.label_embedding(label)
+            c = ops.add_f32(c, self.label_embedding(label))
         elif torch.is_tensor(img_cond):
-            c = c + img_cond.to(x)
+            c = ops.add_f32(c, img_cond.to(x).expand_as(c))
         xin = ops.cast_pad_bf16(x.view(B * T, self.z_dim), ops.pad64(self.z_dim))
         h = ops.gemm_bf16(xin, P["w_in"], P["b_in"], EPI_F32)                       # ln_in
         skips = [h.clone()]

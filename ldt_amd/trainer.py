@@ -71,8 +71,9 @@ class Trainer:
     def score_fn(self, t, x, label=None, condition=None):
         t = t.to(x)
         params = self.model(x, t, label=label, condition=condition)
-        var = self.SDE.var(t)[:, None, None]
-        return -params / torch.sqrt(var), params
+        from . import ops
+        sde = self.SDE                                    # score = -params / sqrt(var(t)), one HIP kernel
+        return ops.vpsde_score(params, t.float(), sde.beta_start, sde.beta_end, sde.sigma2_0), params
 
     @torch.no_grad()
     def sample(self, num_samples, num_points=None, label=None, condition=None, *, x0=None, noise=None, seed=None,
@@ -133,37 +134,87 @@ class Trainer:
         return sample, eps
 
     @torch.no_grad()
-    def valsample(self, batches, batch_size=None, ref=None, save_npy=False):
-        """The reference's validation sampling loop (:167-226): `batches` calls of `sample(batch_size)`, the "Sample rate"
-        print (:206), optionally the `smp_ep<epoch>.npy` dump into cfg.log.save_path (:207-210) and — when reference
-        clouds `ref` (N, points, 3) are given in place of the test loader (datasets are out of scope) — the generation
-        metrics of `compute_all_metrics(smp, ref)` (:217-226) as {"val/gen/<key>": float}.
-        Returns (samples, shapes/second) or, with `ref`, (samples, shapes/second, metrics)."""
-        batch_size = batch_size or self.cfg.data.test_batch_size
-        out, use_time = [], 0.
-        for _ in range(batches):
-            torch.cuda.synchronize()
-            T0 = time.time()
-            smp, _ = self.sample(num_samples=batch_size)
-            torch.cuda.synchronize()
-            use_time += time.time() - T0
-            out.append(smp)
-        smp = torch.cat(out, 0)
-        if ref is not None:
-            smp = smp[:ref.shape[0]]                                                  # :203
-        rate = smp.shape[0] / use_time
-        print("Sample rate: %.8f " % rate)
-        if save_npy:
-            import os
-            import numpy as np
-            np.save(os.path.join(self.cfg.log.save_path, "smp_ep%d" % self.epoch + ".npy"), smp.detach().cpu().numpy())
+    def valsample(self, test_loader, val_cate=0, vis=False, *, batch_size=None, ref=None, save_npy=None):
+        """The reference's validation sampling loop, same signature and return value (trainer/Latent_SDE_Trainer.py:167-226;
+        called as `trainer.valsample(test_loader=test_loader, val_cate=13)` by train_Latent_Diffusion.py:60,85).
+
+        `test_loader` is any iterable of the dataset's dict batches (`te_points`, `tr_points`, `cate_idx`):
+          * `cfg.data.num_categorys == 1` (:173-188): one `sample(num_samples=len(batch['tr_points']))` per batch, the
+            references are the batches' `te_points`;
+          * otherwise (:189-205): the `te_points` whose `cate_idx == val_cate` are the references, and
+            ceil(len(ref) / cfg.data.test_batch_size) label-conditioned batches are sampled and cut to len(ref).
+            (Upstream appends `self.sample(...)`'s (points, eps) TUPLE there and would fail in `torch.cat`; the points are
+            what is meant and what is kept here.)
+        Then, as upstream: the "Sample rate" print (:206), the `smp_ep<epoch>.npy` dump into `cfg.log.save_path`
+        (:207-210), `compute_all_metrics(smp, ref, batch_size=64)` (:217-220), the summary print, and the returned
+        `{"val/gen/<key>": float}` dict.  `vis=True` (mitsuba rendering, :211-216) is out of scope and raises.
+
+        Keyword extensions (not in the reference): `test_loader` may be an int = that many unconditional batches of
+        `batch_size` (default `cfg.data.test_batch_size`) scored against `ref` (N, points, 3) when given; `save_npy`
+        False suppresses the dump, None (default) dumps whenever `cfg.log.save_path` is set.  The samples and the rate of
+        the last call stay available as `self.last_valsample = {"samples", "refs", "rate"}`."""
+        import math
+        import os
+        import numpy as np
+        if vis:
+            raise NotImplementedError("valsample(vis=True): mitsuba rendering (tools/vis_utils.py) is not on this path")
+        self.model.eval()
+        self.compressor.eval()
+        dev = self.device
+        all_ref, all_smp, use_time = [], [], 0.
+
+        def timed_sample(n, label=None):
+            nonlocal use_time
+            _sync(dev)
+            t0 = time.time()
+            pts, _ = self.sample(num_samples=n, label=label)
+            _sync(dev)
+            use_time += time.time() - t0
+            return pts
+
+        if isinstance(test_loader, int):                                   # extension: no dataset at hand
+            bsize = batch_size or self.cfg.data.test_batch_size
+            for _ in range(test_loader):
+                all_smp.append(timed_sample(bsize))
+            smp = torch.cat(all_smp, 0)
+            if ref is not None:
+                ref = ref.to(smp)
+                smp = smp[:ref.shape[0]]
+        elif self.cfg.data.num_categorys == 1:                            # :173-188
+            for data in test_loader:
+                all_ref.append(data["te_points"].to(dev))
+                all_smp.append(timed_sample(data["tr_points"].size(0)))
+            smp, ref = torch.cat(all_smp, 0), torch.cat(all_ref, 0).float()
+        else:                                                              # :189-205
+            for data in test_loader:
+                idx = data["cate_idx"] == val_cate
+                all_ref.append(data["te_points"][idx])
+            ref = torch.cat(all_ref, 0).to(dev).float()
+            bsize = self.cfg.data.test_batch_size
+            for _ in range(math.ceil(ref.shape[0] / bsize)):
+                cates = (torch.ones(bsize) * val_cate).int().to(dev)
+                all_smp.append(timed_sample(bsize, label=cates))
+            if not all_smp:
+                raise ValueError("valsample: no test shape has cate_idx == %r" % (val_cate,))
+            smp = torch.cat(all_smp, 0)[:ref.shape[0]]
+        rate = smp.shape[0] / max(use_time, 1e-9)
+        chief = ldist.world()[0] == 0
+        if chief:
+            print("Sample rate: %.8f " % rate)
+        self.last_valsample = {"samples": smp, "refs": ref, "rate": rate}
+        path = getattr(self.cfg.log, "save_path", "") or ""
+        if save_npy and not path:
+            raise ValueError("valsample(save_npy=True) needs cfg.log.save_path (upstream writes smp_ep<epoch>.npy there)")
+        if chief and path and save_npy is not False:
+            np.save(os.path.join(path, "smp_ep%d" % self.epoch + ".npy"), smp.detach().cpu().numpy())
         if ref is None:
-            return smp, rate
+            return {}
         from .metrics import compute_all_metrics
-        gen_res = compute_all_metrics(smp, ref.to(smp), batch_size=64)
+        gen_res = compute_all_metrics(smp, ref, batch_size=64)
         all_res = {("val/gen/%s" % k): (v if isinstance(v, float) else v.item()) for k, v in gen_res.items()}
-        print("Validation Sample (unit) Epoch:%d " % self.epoch, gen_res)
-        return smp, rate, all_res
+        if chief:
+            print("Validation Sample (unit) Epoch:%d " % self.epoch, gen_res)
+        return all_res
 
     # ---- checkpoints: the reference's dict layout (:228-266) ------------------------------------------
     def resume(self, epoch=None, strict=False, load_optim=True, finetune=False, pretrain=None, **kwargs):
@@ -256,6 +307,11 @@ class CompletionTrainer(Trainer):
         print("Validation Sample (unit) Epoch:%d " % self.epoch, {"cd": float(cd), "f1score": float(f1.mean())})
         return {"cd": float(cd), "f1": float(f1.mean()), "f1score": float(f1.mean()), "rate": smp.shape[0] / max(use_time, 1e-9),
                 "samples": smp, "refs": ref, "parts": part}
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
 
 
 def _rows(t, lo, hi, per):

@@ -85,7 +85,8 @@ def test_compute_all_metrics_keys_and_full_size_smoke():
 
 
 def test_valsample_reports_rate_dump_and_metrics(tiny_cfg, tmp_path):
-    """valsample (reference :167-226): sample-rate print, smp_ep<epoch>.npy dump, compute_all_metrics on given refs."""
+    """valsample (reference :167-226) called the reference's way — a loader of dict batches — on the GPU: sample-rate print,
+    smp_ep<epoch>.npy dump, compute_all_metrics against the batches' te_points; plus the int-loader extension."""
     import copy
     import numpy as np
     import ldt_amd
@@ -94,10 +95,35 @@ def test_valsample_reports_rate_dump_and_metrics(tiny_cfg, tmp_path):
     cfg.sde.sample_N = 30
     torch.manual_seed(0)
     tr = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), ldt_amd.Compressor(cfg.compressor), "cuda:0")
-    ref = torch.randn(5, cfg.data.tr_max_sample_points, 3)
-    smp, rate, res = tr.valsample(2, batch_size=3, ref=ref.cuda(), save_npy=True)
-    assert smp.shape == (5, cfg.data.tr_max_sample_points, 3) and rate > 0
+    P = cfg.data.tr_max_sample_points
+    loader = [{"te_points": torch.randn(3, P, 3), "tr_points": torch.randn(3, P, 3), "cate_idx": torch.zeros(3, dtype=torch.long)},
+              {"te_points": torch.randn(2, P, 3), "tr_points": torch.randn(2, P, 3), "cate_idx": torch.zeros(2, dtype=torch.long)}]
+    res = tr.valsample(test_loader=loader, val_cate=0)
+    smp, rate = tr.last_valsample["samples"], tr.last_valsample["rate"]
+    assert smp.shape == (5, P, 3) and rate > 0 and bool(torch.isfinite(smp).all())
     assert sorted(res) == sorted("val/gen/" + k for k in ("mmd-CD", "cov-CD", "mmd-EMD", "cov-EMD", "1-NN-CD-acc", "1-NN-EMD-acc"))
     assert all(isinstance(v, float) for v in res.values())
     dumped = np.load(tmp_path / ("smp_ep%d.npy" % tr.epoch))
     assert np.array_equal(dumped, smp.cpu().numpy())
+    ref = torch.cat([b["te_points"] for b in loader]).cuda()
+    res2 = tr.valsample(2, batch_size=3, ref=ref, save_npy=False)             # extension: 2 batches of 3, cut to len(ref)
+    assert tr.last_valsample["samples"].shape == (5, P, 3) and sorted(res2) == sorted(res)
+
+
+def test_small_elementwise_entries(tiny_cfg):
+    """ldt_vpsde_score (Trainer.score_fn's -params / sqrt(var(t)), Latent_SDE_Trainer.py:57-61), ldt_add_f32, ldt_widen_bf16."""
+    import ldt_amd
+    from ldt_amd import ops
+    g = torch.Generator().manual_seed(3)
+    params = torch.randn(5, 8, 12, generator=g)
+    t = torch.tensor([1.0, 0.5, 1e-3, 1e-6, 0.25])
+    sde = ldt_amd.DiffusionVPSDE(tiny_cfg.sde)
+    want = -params / torch.sqrt(sde.var(t))[:, None, None]
+    got = ops.vpsde_score(params.cuda(), t.cuda(), sde.beta_start, sde.beta_end, sde.sigma2_0).cpu()
+    var = sde.var(t)
+    tol = (2e-6 + 1.5e-7 / var)[:, None, None]                                # one ulp of exp() moves 1 - exp() by 6e-8 / var relative
+    assert bool(((got - want).abs() <= tol * want.abs()).all())
+    a, b = torch.randn(7, 33, generator=g), torch.randn(7, 33, generator=g)
+    assert torch.equal(ops.add_f32(a.cuda(), b.cuda()).cpu(), a + b)
+    w = torch.randn(9, 64, generator=g).bfloat16()
+    assert torch.equal(ops.widen_bf16(w.cuda()).cpu(), w.float())

@@ -345,3 +345,70 @@ def test_grouper_fragment_image_layout():
                         seen.add(c)
                         assert torch.equal(img[base + step * 4 + blk, 32 * h:32 * h + 32, e], bf(w[32 * blk:32 * blk + 32, c]))
         assert seen == set(range(128))
+
+
+def test_valsample_has_the_reference_signature_and_loader_semantics(tiny_cfg, tmp_path, monkeypatch, capsys):
+    """Trainer.valsample(test_loader, val_cate=0, vis=False) as train_Latent_Diffusion.py:60,85 calls it
+    (trainer/Latent_SDE_Trainer.py:167-226): dict batches, both num_categorys branches, "Sample rate" print,
+    smp_ep<epoch>.npy dump, compute_all_metrics(smp, ref, batch_size=64) -> {"val/gen/<k>": float}.  Host logic only:
+    `sample` and the metric kernels are stubbed (their parity lives in the gpu suite)."""
+    import copy
+    import inspect
+    import ldt_amd
+    import ldt_amd.metrics as Mx
+    sig = inspect.signature(ldt_amd.Trainer.valsample)
+    assert list(sig.parameters)[:4] == ["self", "test_loader", "val_cate", "vis"]
+    assert sig.parameters["val_cate"].default == 0 and sig.parameters["vis"].default is False
+    cfg = copy.deepcopy(tiny_cfg)
+    cfg.log.save_path = str(tmp_path)
+    P = cfg.data.tr_max_sample_points
+    calls, seen = [], {}
+
+    def fake_metrics(smp, ref, batch_size):
+        seen["shapes"] = (tuple(smp.shape), tuple(ref.shape), batch_size)
+        return {"mmd-CD": torch.tensor(0.25), "cov-CD": 0.5}
+
+    monkeypatch.setattr(Mx, "compute_all_metrics", fake_metrics)
+
+    def make(ncat):
+        c = copy.deepcopy(cfg)
+        c.data.num_categorys = ncat
+        c.score.num_categorys = 1
+        tr = ldt_amd.Trainer(c, ldt_amd.Score(c.score), ldt_amd.Compressor(c.compressor), "cpu")
+
+        def fake_sample(num_samples, num_points=None, label=None, condition=None):
+            calls.append((num_samples, None if label is None else label.clone()))
+            return torch.full((num_samples, P, 3), float(len(calls))), torch.zeros(num_samples, 1, 1)
+        tr.sample = fake_sample
+        return tr
+
+    loader = [{"te_points": torch.randn(3, P, 3), "tr_points": torch.randn(3, P, 3), "cate_idx": torch.tensor([13, 2, 13])},
+              {"te_points": torch.randn(2, P, 3), "tr_points": torch.randn(2, P, 3), "cate_idx": torch.tensor([13, 13])}]
+    # single-category branch (:173-188): one sample() per batch, of that batch's size; refs = te_points
+    tr = make(1)
+    res = tr.valsample(test_loader=loader, val_cate=13)                       # exactly the reference's call
+    assert [c[0] for c in calls] == [3, 2] and all(c[1] is None for c in calls)
+    assert res == {"val/gen/mmd-CD": 0.25, "val/gen/cov-CD": 0.5} and all(isinstance(v, float) for v in res.values())
+    assert seen["shapes"] == ((5, P, 3), (5, P, 3), 64)
+    assert "Sample rate:" in capsys.readouterr().out
+    dumped = np.load(tmp_path / ("smp_ep%d.npy" % tr.epoch))
+    assert dumped.shape == (5, P, 3) and np.array_equal(dumped, tr.last_valsample["samples"].numpy())
+    assert torch.equal(tr.last_valsample["refs"], torch.cat([b["te_points"] for b in loader]))
+    # multi-category branch (:189-205): refs = te_points with cate_idx == val_cate, ceil(n / test_batch_size) labelled batches
+    calls.clear()
+    tr = make(55)
+    tr.cfg.data.test_batch_size = 3
+    res = tr.valsample(loader, val_cate=13)
+    assert [c[0] for c in calls] == [3, 3] and all(torch.equal(c[1], torch.full((3,), 13, dtype=torch.int32)) for c in calls)
+    assert seen["shapes"] == ((4, P, 3), (4, P, 3), 64)                      # cut to len(ref)
+    with pytest.raises(ValueError):
+        tr.valsample(loader, val_cate=7)                                      # no shape of that category
+    with pytest.raises(NotImplementedError):
+        tr.valsample(loader, vis=True)                                        # mitsuba rendering: out of scope
+    # keyword extension: int loader = unconditional batches; save_npy=True without a save_path is an error, not a cwd write
+    calls.clear()
+    tr = make(1)
+    tr.cfg.log.save_path = ""
+    assert tr.valsample(2, batch_size=4, save_npy=False) == {} and [c[0] for c in calls] == [4, 4]
+    with pytest.raises(ValueError):
+        tr.valsample(1, batch_size=2, save_npy=True)
