@@ -132,3 +132,50 @@ def test_compressor_fullsize_big_batch_vs_oracle(tokens):
     eps_in[:nb] = ref["all_eps"].cuda()
     dec = comp.sample((B, 2048), given_eps=eps_in)
     assert rel_mse(dec[:nb].cpu(), ref_dec) < 1e-4
+
+
+def test_fullsize_vipc_conditioned_vs_oracle(full):
+    """BASELINE configs[4]'s per-GPU share at the PRODUCTION width (hidden 1024, 16 heads, 24 blocks): B = 32 shapes, T = 32 latent
+    tokens, S = 32 condition tokens — per-sample AdaLN rows (c = t_emb + img_cond, score.py:135) and cross-attention to the
+    point condition on the even blocks (score.py:148-149), synthetic ConditionNet outputs:
+      * teacher-forced Score.forward(condition=(pts_cond, img_cond)) on all 32 samples vs the oracle;
+      * 25 free-running ancestral steps of the FUSED conditional loop (ldt_cond_args: AdaLN rows rebuilt in C++ every step, cached
+        condition K/V) through Trainer.sample with injected noise: every step's latents + the final ones vs the oracle on the first 8
+        samples (trajectories are independent per sample).
+    Bars: relative MSE <= 1e-4 (bf16 operands)."""
+    import ldt_amd
+    O, score = full["O"], full["score"]
+    B, T, S, N, nb = 32, 32, 32, 25, 8
+    cfg = ldt_amd.airplane_config(latent_tokens=T, sample_N=N)
+    z, D = cfg.score.z_dim, cfg.score.hidden_size
+    g = torch.Generator().manual_seed(5)
+    pts_tm = torch.randn(B, S, D, generator=g)                      # token-major [B,S,hidden]; the reference's is (B,hidden,S)
+    img = torch.randn(B, cfg.score.t_dim, generator=g)
+    cond_dev = (pts_tm.transpose(1, 2).contiguous().cuda(), img.cuda())
+    x = torch.randn(B, T, z, generator=g)
+    t = torch.rand(B, generator=g) * 0.98 + 0.01
+    out = score(x.cuda(), t.cuda(), condition=cond_dev)
+    with torch.no_grad():
+        ref = O.score_forward(full["sd_s"], cfg.score, x, t, condition=(pts_tm, img))
+        ref_uncond = O.score_forward(full["sd_s"], cfg.score, x[:2], t[:2])
+    e_fwd = rel_mse(out.cpu(), ref)
+    assert rel_mse(ref[:2], ref_uncond) > 1e-3                      # the condition matters at this size too
+    torch.manual_seed(4)
+    comp = ldt_amd.Compressor(cfg.compressor)                       # a T = 32 compressor (decode only rides along here)
+    comp.init()
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    x0, noises = O.draw_noises(77, B, T, z, N)
+    traj = []
+    pts, eps = tr.sample(B, condition=cond_dev, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    assert pts.shape == (B, cfg.data.tr_max_sample_points, 3) and traj[0].shape == (N, B, T, z)
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda xx, tt: O.score_forward(full["sd_s"], cfg.score, xx, tt, condition=(pts_tm[:nb], img[:nb])))
+    rec = []
+    with torch.no_grad():
+        ref_eps = O.sample_discrete(sde, fn, x0[:nb], [n[:nb] for n in noises], N, record=rec)
+    xs = traj[0][:, :nb].cpu()
+    curve = [rel_mse(xs[i], rec[i][3]) for i in range(N)]
+    e_fin = rel_mse(eps[:nb].cpu(), ref_eps)
+    print("full-size ViPC share (B=32, T=32, S=32): teacher-forced %.3e; fused conditional loop per-step max %.3e, final %.3e"
+          % (e_fwd, max(curve), e_fin))
+    assert e_fwd < 1e-4 and max(curve) < 1e-4 and e_fin < 1e-4, (e_fwd, curve, e_fin)

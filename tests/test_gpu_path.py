@@ -5,7 +5,9 @@ Stated bf16 tolerances (north-star: per-step MSE + final Chamfer), relative MSE 
   * teacher-forced Score output `params`                                      <= 1e-4   (measured ~1e-6)
   * free-running latents, every recorded step and the final x_mean            <= 1e-4   (measured 2.6e-6)
   * decoder on N(0,1)-scale latents (its trained operating range)             <= 1e-4
-  * decoded cloud of the END-TO-END run and its Chamfer distance: self-calibrated.  With random (untrained)
+  * END-TO-END decoded cloud and Chamfer distance with weights TRAINED by the reference's own Trainer.update
+    (tests/golden/trained_tiny.npz; latents at the data scale): points <= 1e-3, CD / mean squared radius <= 1e-3, FIXED
+  * the same with RANDOM weights (a robustness case, not the Chamfer check): self-calibrated.  With random (untrained)
     weights the reverse SDE inflates the latents to rms ~600 (prod 1/sqrt(1-beta_i) = e^5), where the decoder's
     softmaxes saturate and the map is ill-conditioned: the fp32 CPU oracle itself moves by ~7e-3 rel-MSE when
     x0 is perturbed by ONE bf16 rounding (2^-9 relative).  The bar is therefore
@@ -153,6 +155,28 @@ def test_trainer_sample_golden(env, conditioning, use_graph):
     cd = O.chamfer_cd(pts.cpu(), tg["points"])
     radius2 = (tg["points"] ** 2).sum(-1).mean(1)
     assert float((cd / radius2).max()) < max(2e-3, 4 * conditioning["cd"]), conditioning
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_trainer_sample_trained_weights_fixed_bars(tiny_cfg, use_graph):
+    """THE end-to-end points / Chamfer check (north-star: "final Chamfer"): weights trained by the reference's own
+    Trainer.update (oracle/gen_trained_tiny_golden.py), so the sampled latents stay at the data scale (rms 0.5) and the
+    decode is well conditioned.  FIXED bars, no floor multiplier: latents <= 1e-4, decoded points <= 1e-3 relative MSE,
+    Chamfer / mean squared radius <= 1e-3, against what the REFERENCE's Trainer.sample produced on the same draws."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    a, sds = load_golden("trained_tiny")
+    score = ldt_amd.Score(tiny_cfg.score); score.load_state_dict(sds["w"], strict=True)
+    comp = ldt_amd.Compressor(tiny_cfg.compressor); comp.load_state_dict(sds["c"], strict=True)
+    tr = ldt_amd.Trainer(tiny_cfg, score, comp, "cuda:0")
+    worst = max(rel_mse(score(a["step_x"][j].cuda(), a["step_t"][j].cuda()).cpu(), a["step_params"][j]) for j in range(a["step_x"].shape[0]))
+    assert worst < TOL_PARAMS, worst                                     # teacher-forced, the reference's own trajectory
+    B = a["x0"].shape[0]
+    pts, eps = tr.sample(B, x0=a["x0"], noise=a["noises"], use_graph=use_graph)
+    e_lat, e_pts = rel_mse(eps.cpu(), a["eps"]), rel_mse(pts.cpu(), a["points"])
+    cd = O.chamfer_cd(pts.cpu(), a["points"]) / (a["points"] ** 2).sum(-1).mean(1)
+    print("trained-tiny end to end: latents %.2e points %.2e chamfer/r2 %.2e" % (e_lat, e_pts, float(cd.max())))
+    assert e_lat < 1e-4 and e_pts < 1e-3 and float(cd.max()) < 1e-3, (e_lat, e_pts, float(cd.max()))
 
 
 def test_free_running_per_step_curve(env):

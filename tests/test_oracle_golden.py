@@ -121,6 +121,26 @@ def test_trainer_sample_and_trajectory(tiny_cfg):
     assert rel_mse(pts, a["points"]) < 1e-8
 
 
+def test_trained_tiny_end_to_end(tiny_cfg):
+    """The well-conditioned fixture: weights trained by the reference's own Trainer.update for 600 CPU iterations
+    (oracle/gen_trained_tiny_golden.py), sampled by the reference's Trainer.sample — latents at the data scale."""
+    a, sds = load_golden("trained_tiny")
+    N = int(a["N"])
+    assert N == tiny_cfg.sde.sample_N and float(a["latent_rms"]) < 1.0 and float(a["train_loss_last"]) < 0.5 * float(a["train_loss_first"])
+    x0, noises = O.draw_noises(1234, *a["x0"].shape, N)
+    assert torch.equal(x0, a["x0"]) and torch.equal(torch.stack(noises), a["noises"])
+    for j in range(a["step_x"].shape[0]):
+        p = O.score_forward(sds["w"], tiny_cfg.score, a["step_x"][j], a["step_t"][j])
+        assert rel_mse(p, a["step_params"][j]) < TOL, j
+    pts, eps = O.trainer_sample(sds["w"], sds["c"], tiny_cfg, a["x0"], list(a["noises"]))
+    assert rel_mse(eps, a["eps"]) < 1e-9 and rel_mse(pts, a["points"]) < 1e-9
+    # and the map IS well conditioned here: one bf16 rounding of x0 moves the decoded cloud by < 1e-4 (random weights: 7e-3)
+    g = torch.Generator().manual_seed(0)
+    x0p = a["x0"] * (1 + 2 ** -9 * torch.randn(a["x0"].shape, generator=g))
+    pts_p, _ = O.trainer_sample(sds["w"], sds["c"], tiny_cfg, x0p, list(a["noises"]))
+    assert rel_mse(pts_p, a["points"]) < 1e-4
+
+
 def test_other_predictors(tiny_cfg):
     a, _ = load_golden("other_predictors")
     t, _ = load_golden("trainer_sample_tiny")
