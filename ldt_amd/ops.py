@@ -209,10 +209,12 @@ def philox_normal(shape, device, seed, step=0, elem_offset=0):
 
 
 # ----------------------------------------------------------------------------- Compressor encoder front end
-# Upstream pointnet2_ops (the library the reference calls for FPS; not vendored, not importable here — SURVEY §8c) ignores
-# points with |p|^2 <= 1e-3; the reference's vendored twin (model/functional/src/sampling/sampling.cu) does not.  Default:
-# the twin.  Flip this (or LDT_FPS_SKIP_NEAR_ORIGIN=1, or pass skip_near_origin=) for a real-checkpoint comparison.
-FPS_SKIP_NEAR_ORIGIN = bool(int(__import__("os").environ.get("LDT_FPS_SKIP_NEAR_ORIGIN", "0")))
+# Upstream pointnet2_ops (the library every FPS call of the reference goes through — Compressor/layers.py:106, completion
+# valsample :182-183; not vendored, not importable here — SURVEY §8c) ignores points with |p|^2 <= 1e-3; the reference's
+# vendored twin (model/functional/src/sampling/sampling.cu) does not.  Default: upstream's rule ON (what a real checkpoint was
+# trained with: centred ShapeNet clouds do have points that close to the origin).  LDT_FPS_SKIP_NEAR_ORIGIN=0, this flag, or
+# skip_near_origin=False give the twin's behaviour.
+FPS_SKIP_NEAR_ORIGIN = bool(int(__import__("os").environ.get("LDT_FPS_SKIP_NEAR_ORIGIN", "1")))
 
 
 def fps(xyz, m, skip_near_origin=None):

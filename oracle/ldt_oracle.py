@@ -391,7 +391,12 @@ def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
 # ----------------------------------------------------------------------------- Compressor: encode
 
 
-def fps(xyz, m, skip_near_origin=False):
+# Default of the near-origin rule: ON, as in upstream pointnet2_ops (the library every FPS call of the reference goes through:
+# Compressor/layers.py:106, completion valsample :182-183); False = the vendored twin's behaviour (sampling.cu has no such rule).
+FPS_SKIP_NEAR_ORIGIN = True
+
+
+def fps(xyz, m, skip_near_origin=None):
     """Farthest point sampling, restating model/functional/src/sampling/sampling.cu:86-167
     (the vendored twin of pointnet2_ops' kernel; **parity unpinned**, see module header).
     Start index 0; distances init 1e38 (sampling.cpp:53-54); running min; argmax; ties go to the
@@ -400,6 +405,8 @@ def fps(xyz, m, skip_near_origin=False):
     skip_near_origin: what upstream pointnet2_ops (the library the reference really calls, model/Compressor/layers.py:106;
     not vendored — behaviour restated from its published kernel, unverifiable here) does in addition: points with
     |p|^2 <= 1e-3 neither update their distance nor can be selected (argmax starts from (best = -1, index 0))."""
+    if skip_near_origin is None:
+        skip_near_origin = FPS_SKIP_NEAR_ORIGIN
     xyz = np.ascontiguousarray(xyz.detach().cpu().numpy(), dtype=np.float32)
     b, n, _ = xyz.shape
     out = np.zeros((b, m), dtype=np.int64)

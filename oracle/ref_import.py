@@ -32,9 +32,17 @@ def available() -> bool:
     return os.path.isdir(os.path.join(REF_ROOT, "model", "scorenet"))
 
 
-def fps_numpy(xyz: np.ndarray, m: int) -> np.ndarray:
-    """FPS exactly as sampling.cu:86-167 (start idx 0, dist init 1e38, running
-    min, argmax with the 512-thread tie order: smaller (k % 512, k // 512) wins)."""
+def fps_numpy(xyz: np.ndarray, m: int, skip_near_origin: bool = True) -> np.ndarray:
+    """FPS as sampling.cu:86-167 (start idx 0, dist init 1e38, running min, argmax with the 512-thread tie order: smaller
+    (k % 512, k // 512) wins) + what the upstream pointnet2_ops kernel the reference really calls does in addition
+    (restated from its published source, not vendored): points with |p|^2 <= 1e-3 are skipped — they neither
+    update their distance nor can be selected.  Delegates to the oracle's restatement (one implementation)."""
+    from oracle.ldt_oracle import fps as oracle_fps
+    return oracle_fps(torch.from_numpy(np.asarray(xyz, dtype=np.float32)), int(m), skip_near_origin=skip_near_origin).numpy()
+
+
+def _fps_numpy_twin_only(xyz: np.ndarray, m: int) -> np.ndarray:
+    """(kept for reference: the vendored twin alone, no near-origin skip — what rounds 1-2 captured the goldens with)"""
     b, n, _ = xyz.shape
     out = np.zeros((b, m), dtype=np.int64)
     k = np.arange(n)

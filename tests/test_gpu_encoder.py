@@ -45,7 +45,7 @@ def test_fps_ties_and_start(mods):
 
 def test_fps_skip_near_origin(mods):
     """The upstream pointnet2_ops variant: points with |p|^2 <= 1e-3 are never selected and never update their
-    distance; default stays the vendored twin.  GPU == oracle restatement, both switch positions, many clouds at once."""
+    distance; ON by default, off = the vendored twin.  GPU == oracle restatement, both switch positions, many clouds at once."""
     ops, O = mods
     g = torch.Generator().manual_seed(4)
     p = torch.randn(6, 700, 3, generator=g) * 0.4
@@ -58,7 +58,8 @@ def test_fps_skip_near_origin(mods):
         assert torch.equal(out.cpu().long(), ref)
     picked = O.gather(p, O.fps(p, 64, skip_near_origin=True))[:, 1:]
     assert float((picked ** 2).sum(-1).min()) > 1e-3       # none of the skipped points was chosen
-    assert not torch.equal(O.fps(p, 640, skip_near_origin=True), O.fps(p, 640))
+    assert not torch.equal(O.fps(p, 640), O.fps(p, 640, skip_near_origin=False))          # default = upstream's rule
+    assert torch.equal(ops.fps(p.cuda(), 64).cpu().long(), O.fps(p, 64, skip_near_origin=True))         # product default too
     z = torch.zeros(1, 40, 3)                               # every point skipped: the kernel keeps returning index 0
     assert ops.fps(z.cuda(), 5, skip_near_origin=True)[0].tolist() == [0, 0, 0, 0, 0] == O.fps(z, 5, skip_near_origin=True)[0].tolist()
 
@@ -146,6 +147,25 @@ def test_compressor_forward_golden(tiny_cfg):
     assert rel_mse(out["set"].cpu(), a["set"]) < 1e-3
     eps2 = comp.encode(a["pts"].cuda(), post_noise=list(a["post_noise"]))
     assert torch.equal(eps2, out["all_eps"])
+
+
+def test_compressor_forward_near_origin_points_golden(tiny_cfg):
+    """Clouds with points inside the |p|^2 <= 1e-3 ball: by default FPS follows upstream pointnet2_ops (never picks them) and the
+    encode equals what the reference's Compressor.forward produced with that rule (compressor_fwd_origin.npz); with the
+    vendored twin's rule (skip_near_origin off) the centres are the twin's — and different."""
+    import ldt_amd
+    from ldt_amd import ops
+    a, _ = load_golden("compressor_fwd_origin")
+    _, csd = load_golden("trainer_sample_tiny")
+    comp = ldt_amd.Compressor(tiny_cfg.compressor)
+    comp.load_state_dict(csd["c"], strict=True)
+    comp = comp.cuda()
+    out = comp(a["pts"].cuda(), post_noise=list(a["post_noise"]))
+    assert torch.equal(out["fps_idx"].cpu().long(), a["fps_idx"].long())
+    assert torch.equal(out["knn_idx"].cpu().long().sort(-1)[0], a["knn_idx"].long().sort(-1)[0])
+    assert rel_mse(out["all_eps"].cpu(), a["all_eps"]) < 1e-3 and rel_mse(out["set"].cpu(), a["set"]) < 1e-3
+    twin = ops.fps(a["pts"].cuda(), tiny_cfg.compressor.z_scales, skip_near_origin=False).cpu().long()
+    assert torch.equal(twin, a["fps_idx_twin"].long()) and not torch.equal(twin, a["fps_idx"].long())
 
 
 def test_encode_decode_roundtrip_shapes_full_size():

@@ -256,6 +256,19 @@ def test_encoder(tiny_cfg):
     assert abs(float(r["max"]) - float(a["max"])) < 1e-4 * abs(float(a["max"]))
 
 
+def test_compressor_encode_near_origin_points(tiny_cfg):
+    """The encode golden whose clouds hold points inside the |p|^2 <= 1e-3 ball (FPS with upstream pointnet2_ops' skip rule,
+    the oracle's default): centres, latents and reconstruction vs the reference's Compressor.forward."""
+    a, _ = load_golden("compressor_fwd_origin")
+    sd = load_golden("trainer_sample_tiny")[1]["c"]
+    cc = tiny_cfg.compressor
+    assert O.FPS_SKIP_NEAR_ORIGIN is True
+    assert torch.equal(O.fps(a["pts"], cc.z_scales), a["fps_idx"].long())
+    assert torch.equal(O.fps(a["pts"], cc.z_scales, skip_near_origin=False), a["fps_idx_twin"].long())
+    r = O.compressor_encode(sd, cc, a["pts"], list(a["post_noise"]))
+    assert rel_mse(r["all_eps"], a["all_eps"]) < 1e-9 and rel_mse(r["set"], a["set"]) < 1e-9
+
+
 def test_fps_tie_break_and_start():
     """Exact ties (duplicate points): index 0 is always first (sampling.cu:105-107); a tie goes to
     the smaller (k % 512, k // 512) — the 512-thread strided scan + pairwise tree (:141-158)."""
