@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 12
+#define LDT_ABI_VERSION 13
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -163,6 +163,11 @@ int ldt_vpsde_score(const float* params, const float* t, float beta0, float beta
 int ldt_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
 
+/* LN-folding monitor: *out = max over the M rows of mean^2 / variance, from the row statistics stats[parts][M][2] a
+ * ldt_gemm_resid_lnstats launch wrote (K = parts * 256 channels).  The folded projections' rounding error grows as
+ * (1 + mean^2 / variance); the sampler falls back to the LayerNorm kernels when this exceeds its bound. */
+int ldt_fold_mean_ratio(const float* stats, int32_t parts, int64_t M, int32_t K, float* out, void* stream);
+
 /* ---- Compressor encoder front end (model/Compressor/layers.py:65-112, 288-319; Network.py:26-29,76,86-107) ----
  * Clouds are fp32 [B][n][3]; index outputs are int32.
  * ldt_fps: farthest point sampling, m centres per cloud, semantics of the vendored CUDA twin
@@ -294,6 +299,11 @@ typedef struct ldt_score_plan {
        streams give each plan 128: their kernels then share the chip CU-wise and one stream's HBM-bound epilogues /
        attention overlap the other's MFMA-bound main loops (ldt_amd/diffusion.py, `streams`). */
     int32_t gemm_wgs; int32_t _pad1;
+    /* Optional LN-folding monitor (NULL = off): one device float, raised (atomic max; zero it first) after every folded
+       residual GEMM of a forward to max over rows of mean^2 / variance of that GEMM's output — the quantity that scales
+       the folded projections' rounding error, (1 + mean^2 / variance) x the LayerNorm kernel's.  The sampler sets it on a
+       probe forward before and after the loop (ldt_amd/diffusion.py) and leaves it NULL inside the loop. */
+    float* fold_monitor;
 } ldt_score_plan;
 
 /* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */

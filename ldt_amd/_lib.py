@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -31,7 +31,7 @@ class ScorePlan(C.Structure):
         + [("w_q", _vp * MAX_BLOCKS), ("b_q", _vp * MAX_BLOCKS), ("kv_cond", _vp * MAX_BLOCKS), ("cond_tokens", _i32), ("_pad0", _i32)]
         + [("mod", _vp), ("mod_step_stride", _i64), ("mod_sample_stride", _i64)]
         + [(n, _vp) for n in ("xin", "X", "Hb", "QKV", "Ob", "U")]
-        + [("fold", _vp), ("fold_step_stride", _i64), ("stats", _vp), ("gemm_wgs", _i32), ("_pad1", _i32)]
+        + [("fold", _vp), ("fold_step_stride", _i64), ("stats", _vp), ("gemm_wgs", _i32), ("_pad1", _i32), ("fold_monitor", _vp)]
     )
 
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "ldt_vpsde_score": [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
     "ldt_add_f32": [_vp, _vp, _vp, _i64, _vp],
     "ldt_widen_bf16": [_vp, _vp, _i64, _vp],
+    "ldt_fold_mean_ratio": [_vp, _i32, _i64, _i32, _vp, _vp],
     "ldt_fps": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ldt_norm_points": [_vp, _i32, _i32, _vp, _vp],
     "ldt_mixture_seed": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp],

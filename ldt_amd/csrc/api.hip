@@ -318,13 +318,17 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D,
                         BFM(p->Hb), D, m + 4 * D, tstr, p->stats};
             go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
+            if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, D / 256, M, D, p->fold_monitor, s));
             GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, nullptr, p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, F, D,
                         nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl + 6L * D, fl + 6L * D + F, fstep};
             gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
             GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F,
                         BFM(p->Hb), D, m + 6 * D + D, tstr, p->stats};      // next block's scale_msa
             gd.max_wgs = p->gemm_wgs;
-            if (l + 1 < p->blocks) LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
+            if (l + 1 < p->blocks) {
+                LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
+                if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, D / 256, M, D, p->fold_monitor, s));
+            }
             else LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
             continue;
         }

@@ -187,3 +187,53 @@ extern "C" int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* 
                        reinterpret_cast<const bf16_t*>(src), dst, (long)n);
     return ldt_check_launch("widen_bf16");
 }
+
+// ------------------------------------------------------------------------------------------------
+// LN-folding monitor: max over rows of mean^2 / variance from the producer's row statistics stats[parts][M][2] (partial
+// (sum, sum of squares) per 256-column tile).  The folded projections round x (1 + scale) to bf16 BEFORE the mean is removed,
+// so their error variance is (1 + mean^2 / variance) x the LayerNorm kernel's; the sampler reads this once per
+// sample() call and falls back to the LayerNorm kernels when the ratio says the 1e-4 parity bar is at risk.
+// One workgroup of 256 threads, fixed order: deterministic.  *out = the maximum ratio (0 when M == 0).
+__global__ __launch_bounds__(256) void fold_mean_ratio_kernel(const float* __restrict__ stats, int parts, long M, int K, float* __restrict__ out) {
+    float best = 0.f;
+    const float invk = 1.0f / (float)K;
+    for (long r = threadIdx.x; r < M; r += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int p = 0; p < parts; ++p) { s1 += stats[((long)p * M + r) * 2]; s2 += stats[((long)p * M + r) * 2 + 1]; }
+        const float mean = s1 * invk;
+        const float var = fmaxf(s2 * invk - mean * mean, 0.f) + 1e-6f;
+        best = fmaxf(best, mean * mean / var);
+    }
+    best = wave_max(best);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+// the same, accumulated into *out by atomic max (ratios are non-negative: their bit patterns order like ints); the Score
+// forward calls it after every folded residual GEMM when plan->fold_monitor is set
+__global__ __launch_bounds__(256) void fold_monitor_kernel(const float* __restrict__ stats, int parts, long M, int K, float* __restrict__ out) {
+    float best = 0.f;
+    const float invk = 1.0f / (float)K;
+    for (long r = blockIdx.x * 256L + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int p = 0; p < parts; ++p) { s1 += stats[((long)p * M + r) * 2]; s2 += stats[((long)p * M + r) * 2 + 1]; }
+        const float mean = s1 * invk;
+        const float var = fmaxf(s2 * invk - mean * mean, 0.f) + 1e-6f;
+        best = fmaxf(best, mean * mean / var);
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(best));
+}
+int ldt_fold_monitor_launch(const float* stats, int parts, long M, int K, float* out, hipStream_t s) {
+    long blocks = (M + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(fold_monitor_kernel, dim3((unsigned)blocks), dim3(256), 0, s, stats, parts, M, K, out);
+    return ldt_check_launch("fold_monitor");
+}
+
+extern "C" int ldt_fold_mean_ratio(const float* stats, int32_t parts, int64_t M, int32_t K, float* out, void* stream) {
+    LDT_REQUIRE(stats && out && parts >= 1 && M > 0 && K > 0, LDT_EARG, "fold_mean_ratio: bad argument");
+    hipLaunchKernelGGL(fold_mean_ratio_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats, parts, (long)M, K, out);
+    return ldt_check_launch("fold_mean_ratio");
+}

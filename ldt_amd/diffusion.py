@@ -225,6 +225,9 @@ class DiffusionVPSDE:
                 if shared:
                     if fold is None and model.can_fold(Bs, T, wgs):
                         fold = model.fold_table(mod)                                  # (+ the LN-folding S / C rows)
+                        # guard: a monitored forward on the first sub-batch at step 0 (0.1 % of a 1000-step call); rows whose
+                        # mean dwarfs their spread switch this model to the LayerNorm kernels (Score.fold_probe)
+                        model.fold_probe(xs, 0, mod, fold)
                     plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if model.can_fold(Bs, T, wgs) else None, slot=i, gemm_wgs=wgs)
                 else:
                     c_buf = torch.empty((Bs, model.t_dim), dtype=torch.float32, device=dev)
@@ -277,6 +280,8 @@ class DiffusionVPSDE:
                 main.synchronize()                                                    # scratch / sub-streams must outlive the loop
             if trajectory is not None:
                 trajectory.append(torch.cat([j[-1] for j in jobs], 1))
+            if fold is not None and model.can_fold(bounds[1], T, 0 if streams == 1 else max(256 // streams, 1)):
+                model.fold_probe(x[:bounds[1]], N - 1, mod, fold)                     # and on the finished latents (affects later calls)
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)

@@ -106,6 +106,16 @@ def gemm_lnfold(xs, w, stats, fold_s, fold_c, epilogue=EPI_BF16, step_ptr=None, 
     return out
 
 
+def fold_mean_ratio(stats, K):
+    """max over rows of mean^2 / variance from producer row statistics stats [K/256, M, 2] (one host sync)."""
+    _need(stats, torch.float32, "stats")
+    if stats.dim() != 3 or stats.shape[2] != 2 or not stats.is_contiguous():
+        raise ValueError("fold_mean_ratio: stats must be contiguous [parts, M, 2]")
+    out = torch.zeros(1, dtype=torch.float32, device=stats.device)
+    check(lib().ldt_fold_mean_ratio(_p(stats), stats.shape[0], stats.shape[1], int(K), _p(out), stream_ptr()), "ldt_fold_mean_ratio")
+    return float(out.item())
+
+
 def layernorm_modulate(x, w=None, b=None, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=0,
                        step_ptr=None, mod_step_stride=0, out=None):
     """x fp32 [M,C] -> bf16 [M,C]: LN(eps 1e-6)[*w+b] then *(1+scale)+shift (per-sample vectors)."""

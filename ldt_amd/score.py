@@ -69,6 +69,8 @@ class Score(nn.Module):
         self._ws = {}
         self._freq = None
         self._cond_cache = {}
+        self._fold_disabled = False      # set by fold_probe when a row's mean^2 / variance exceeds FOLD_MAX_MEAN_RATIO
+        self.fold_ratio_seen = 0.0       # largest mean^2 / variance the probes have measured (diagnostic)
 
     # ------------------------------------------------------------------ packed weights
     @property
@@ -197,7 +199,7 @@ class Score(nn.Module):
             }
         return self._ws[k]
 
-    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0):
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0, monitor=None):
         """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows};
         fold: the `fold_table(mod)` of a batch-shared `mod` (enables the LN-folded GEMM epilogues); slot / gemm_wgs: workspace
         set and persistent-grid cap of a sub-batch that shares the GPU with another stream (diffusion.py, `streams`)."""
@@ -225,7 +227,9 @@ class Score(nn.Module):
             if mod_sample_stride != 0:
                 raise ValueError("LN folding needs batch-shared modulation (mod_sample_stride == 0)")
             p.fold, p.fold_step_stride, p.stats = fold.data_ptr(), fold.stride(0), W["stats"].data_ptr()
-        p._keep = (P, W, mod, kv_cond, fold)   # keep the buffers alive as long as the plan
+            if monitor is not None:
+                p.fold_monitor = monitor.data_ptr()
+        p._keep = (P, W, mod, kv_cond, fold, monitor)   # keep the buffers alive as long as the plan
         return p
 
     # ------------------------------------------------------------------ AdaLN tables
@@ -263,10 +267,39 @@ class Score(nn.Module):
         launches measured 3 % faster.  LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
+        if self._fold_disabled and mode != 2:
+            return False
         if mode == 0 or self.unet or D % 256 or D > 1024 or M % 256 or self.Transformer[0].mlp.out.in_channels % 256:
             return False
         lim = gemm_wgs if 0 < gemm_wgs < 256 else 256
         return mode == 2 or (M // 256) * (D // 256) * 8 >= lim * 5
+
+    # The folded projections round x (1 + scale) to bf16 BEFORE the row mean is removed: their operand-rounding error is
+    # (1 + mean^2 / variance) x the LayerNorm kernel's (tests/test_gpu_kernels.py::test_gemm_lnfold_error_law_vs_row_mean:
+    # 1.3e-6 relative MSE per projection at mean = 0, 2.2e-5 at |mean| = 4 std, 8.5e-5 at 8 std).  Past this bound
+    # (|mean| > 4 std on any row of any block) the sampler uses the LayerNorm kernels, which do not have the term.
+    FOLD_MAX_MEAN_RATIO = 16.0
+
+    def fold_probe(self, x, step_index, mod, fold):
+        """One monitored Score forward on latents `x` (B, T, z) at row `step_index` of the batch-shared tables: returns the
+        largest mean^2 / variance over every row of every folded LayerNorm input (ldt_score_plan.fold_monitor) and disables
+        folding for this model when it exceeds FOLD_MAX_MEAN_RATIO (LDT_LN_FOLD=2 keeps it forced on)."""
+        B, T, _ = x.shape
+        mon = torch.zeros(1, dtype=torch.float32, device=x.device)
+        step = torch.full((1,), int(step_index), dtype=torch.int32, device=x.device)
+        plan = self.plan(B, T, mod, self.n_mod, 0, fold=fold, slot=0, monitor=mon)   # (runs before / after the loop on the same stream: shares its workspace)
+        out = torch.empty_like(x)
+        check(lib().ldt_score_forward(ctypes.byref(plan), x.contiguous().data_ptr(), out.data_ptr(), step.data_ptr(), ops.stream_ptr()),
+              "ldt_score_forward")
+        ratio = float(mon.item())
+        self.fold_ratio_seen = max(self.fold_ratio_seen, ratio)
+        if ratio > self.FOLD_MAX_MEAN_RATIO and not self._fold_disabled:
+            import warnings
+            self._fold_disabled = True
+            warnings.warn("ldt_amd.Score: a LayerNorm input row has mean^2 / variance = %.1f (> %.0f): the LN-folded GEMM epilogues "
+                          "would lose accuracy there; using the LayerNorm kernels from now on (LDT_LN_FOLD=2 forces folding)"
+                          % (ratio, self.FOLD_MAX_MEAN_RATIO))
+        return ratio
 
     def fold_table(self, mod):
         """Per-step S / C vectors of the LN-folded projections (include/ldt_hip.h, ldt_gemm_resid_lnstats), fp32

@@ -179,3 +179,49 @@ def test_fullsize_vipc_conditioned_vs_oracle(full):
     print("full-size ViPC share (B=32, T=32, S=32): teacher-forced %.3e; fused conditional loop per-step max %.3e, final %.3e"
           % (e_fwd, max(curve), e_fin))
     assert e_fwd < 1e-4 and max(curve) < 1e-4 and e_fin < 1e-4, (e_fwd, curve, e_fin)
+
+
+def test_fullsize_lnfold_massive_activation_and_row_offset_guard(full):
+    """LN folding at the production size under hostile residual streams:
+      (a) a "massive activation" channel (ln_in bias + 60 on ONE channel: the classic trained-transformer outlier) inflates a
+          row's variance, not its mean / std ratio — the folded path stays within 1e-4 of the oracle;
+      (b) a COMMON offset (ln_in bias + 6 on every channel: |mean| ~ 6 std) is what the folded form is sensitive to (error x
+          (1 + mean^2 / var)): the monitored probe forward reports mean^2 / var > Score.FOLD_MAX_MEAN_RATIO, folding is
+          switched off for the model, and sampling through the LayerNorm kernels stays within 1e-4."""
+    import warnings
+    O, cfg, score = full["O"], full["cfg"], full["score"]
+    B, T, z, nb = 64, 256, cfg.score.z_dim, 4
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, T, z, generator=g)
+    bias0 = score.ln_in.bias.detach().clone()
+    sd = dict(full["sd_s"])
+    try:
+        # (a) one massive channel
+        b = bias0.clone(); b[123] += 60.0
+        score.ln_in.bias.data.copy_(b); sd["ln_in.bias"] = b.cpu()
+        assert score.can_fold(B, T)
+        folded = score.forward_shared_t(x.cuda(), 0.5)
+        with torch.no_grad():
+            ref = O.score_forward(sd, cfg.score, x[:nb], torch.full((nb,), 0.5))
+        e_a = rel_mse(folded[:nb].cpu(), ref)
+        # (b) common offset
+        b = bias0 + 6.0
+        score.ln_in.bias.data.copy_(b); sd["ln_in.bias"] = b.cpu()
+        _, mod = score.time_table(torch.tensor([0.5], device="cuda"))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ratio = score.fold_probe(x.cuda(), 0, mod, score.fold_table(mod))
+        assert ratio > score.FOLD_MAX_MEAN_RATIO and score._fold_disabled and not score.can_fold(B, T) and len(w) == 1
+        out = score.forward_shared_t(x.cuda(), 0.5)                 # now on the LayerNorm kernels
+        with torch.no_grad():
+            ref_b = O.score_forward(sd, cfg.score, x[:nb], torch.full((nb,), 0.5))
+        e_b = rel_mse(out[:nb].cpu(), ref_b)
+        forced = score.forward_shared_t(x.cuda(), 0.5, fold=True)   # what folding would have cost here
+        e_forced = rel_mse(forced[:nb].cpu(), ref_b)
+        print("LN-fold robustness at full size: massive channel folded %.2e; common offset (mean^2/var = %.1f): LayerNorm kernels %.2e, "
+              "folding forced %.2e" % (e_a, ratio, e_b, e_forced))
+        assert e_a < 1e-4 and e_b < 1e-4
+    finally:
+        score.ln_in.bias.data.copy_(bias0)
+        score._fold_disabled = False
+        score.packed()

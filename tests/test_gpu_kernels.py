@@ -112,6 +112,40 @@ def test_gemm_lnfold_pair(M, D, N2, gelu):
     assert e_fold < 3e-5 and e_fold < 4 * e_ln + 1e-6, (e_fold, e_ln)
 
 
+@pytest.mark.parametrize("ratio", [0.0, 2.0, 4.0, 8.0])
+def test_gemm_lnfold_error_law_vs_row_mean(ratio):
+    """The folded form rounds xs = x (1 + scale) to bf16 BEFORE the row mean is removed, so its error variance is
+    (1 + mu^2 / sigma^2) x that of rounding the centred value (DESIGN.md §4 "LN folding").  Rows with |mean| / std = ratio:
+    the measured error follows the law (within 2x), stays below the 1e-4 parity bar up to |mean| = 4 std, and the row-offset
+    monitor the sampler consults (ops.fold_mean_ratio -> Score.can_fold) reports mu^2 / sigma^2."""
+    from ldt_amd._lib import EPI_BF16
+    M, D, N2, K1 = 512, 1024, 1024, 256
+    g = torch.Generator().manual_seed(int(ratio * 10) + 5)
+    a = bf(torch.randn(M, K1, generator=g)); wo = bf(torch.randn(D, K1, generator=g) / K1 ** 0.5 * 0.05); bo = torch.zeros(D)
+    x0 = torch.randn(M, D, generator=g) + ratio                        # sigma = 1, row mean = ratio
+    sc = 0.2 * torch.randn(D, generator=g); sh = 0.2 * torch.randn(D, generator=g)
+    w2 = bf(torch.randn(N2, D, generator=g) / D ** 0.5); b2 = torch.randn(N2, generator=g)
+    xd = dev(x0.clone())
+    xs, stats = ops.gemm_resid_lnstats(dev(a, torch.bfloat16), dev(wo, torch.bfloat16), dev(bo), xd, dev(sc))
+    S = (w2.double() * (1 + sc.double())).sum(1).float(); C = (w2.double() @ sh.double() + b2.double()).float()
+    y = ops.gemm_lnfold(xs, dev(w2, torch.bfloat16), stats, dev(S), dev(C), EPI_BF16)
+    xn = xd.cpu().double()
+    h = (xn - xn.mean(1, keepdim=True)) / torch.sqrt(xn.var(1, unbiased=False, keepdim=True) + 1e-6) * (1 + sc.double()) + sh.double()
+    ref = h @ w2.double().T + b2.double()
+    hb = ops.layernorm_modulate(xd, shift=dev(sh), scale=dev(sc), rows_per_sample=M)
+    y0 = ops.gemm_bf16(hb, dev(w2, torch.bfloat16), dev(b2), EPI_BF16)
+    e_fold, e_ln = rel_mse(y.float().cpu(), ref), rel_mse(y0.float().cpu(), ref)
+    # the bf16 OUTPUT rounding is common to both; what differs is the operand rounding, which obeys the law
+    out_round = rel_mse(ref.float().bfloat16().double(), ref)
+    law = (1 + ratio ** 2) * max(e_ln - out_round, 2e-7) + out_round
+    print("LN-fold error law, |mean|/std = %g: folded %.2e, LayerNorm kernel %.2e, law predicts %.2e" % (ratio, e_fold, e_ln, law))
+    assert e_fold < 2.0 * law + 1e-6, (e_fold, e_ln, law)
+    if ratio <= 4.0:
+        assert e_fold < 1e-4
+    mon = ops.fold_mean_ratio(stats, D)
+    assert abs(mon - ratio ** 2) < 0.15 * ratio ** 2 + 0.05, mon
+
+
 def test_gemm_lnfold_rejects_bad_shapes():
     from ldt_amd._lib import LdtHipError
     x = torch.zeros(256, 512, dtype=torch.bfloat16, device="cuda"); w = torch.zeros(300, 512, dtype=torch.bfloat16, device="cuda")
