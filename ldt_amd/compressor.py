@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import ACT_NONE, ACT_RELU, ACT_SILU
+from ._lib import ACT_NONE, ACT_RELU, ACT_SILU, LdtHipError
 from .blocks import final_layer, pack_block, pack_final, residual_block
 from .layers import ActNorm, FinalLayer, LabelEmbedding, MLP, ResidualBlock, _Holder, conv_w, params_fingerprint
 
@@ -123,11 +123,18 @@ def run_grouper(G, pts, feat, groups, k):
     fps_idx = ops.fps(pts, groups)
     centers = ops.gather_rows(pts, fps_idx)                                     # [B,S,3]
     knn_idx = ops.knn(pts, centers, k)
+    global FUSED_GROUPER
     if FUSED_GROUPER and "wimg" in G and (k in (8, 16) or k % 32 == 0) and feat.shape[2] == 128:
-        # grouped rows, the three pointwise layers and the max over neighbours in one kernel: no [B*S*k, .] tensor exists
-        tok = ops.grouper_mlp(feat.contiguous(), pts.contiguous(), fps_idx, knn_idx, G["alpha"], G["beta"], G["wimg"],
-                              G["b_pre1"], G["b_pre2"], G["b_pre3"])
-        return centers, tok, fps_idx, knn_idx
+        # grouped rows, the three pointwise layers and the max over neighbours in one kernel: no [B*S*k, .] tensor exists.
+        # (Its fmaxf neighbour max + ReLU turn NaN activations into finite values; the chain's max-pool would propagate them.)
+        try:
+            tok = ops.grouper_mlp(feat.contiguous(), pts.contiguous(), fps_idx, knn_idx, G["alpha"], G["beta"], G["wimg"],
+                                  G["b_pre1"], G["b_pre2"], G["b_pre3"])
+            return centers, tok, fps_idx, knn_idx
+        except LdtHipError as e:                                    # e.g. hipFuncSetAttribute refusing 138 KB of dynamic LDS
+            import warnings
+            FUSED_GROUPER = False                                   # once per process: the five-kernel chain computes the same tokens
+            warnings.warn("ldt_amd: fused grouper kernel unavailable (%s); using the group_normalize + GEMM chain" % e)
     U = ops.group_normalize(feat, pts, fps_idx, knn_idx, G["alpha"], G["beta"], normalize=G["normalize"])
     h1 = ops.gemm_bf16(U, G["w_pre1"], G["b_pre1"], EPI_RELU_BF16)              # transfer: Conv+BN+ReLU
     r = ops.gemm_bf16(h1, G["w_pre2"], G["b_pre2"], EPI_RELU_BF16)              # net1: Conv+BN+ReLU

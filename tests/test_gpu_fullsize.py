@@ -195,10 +195,15 @@ def test_fullsize_lnfold_massive_activation_and_row_offset_guard(full):
     x = torch.randn(B, T, z, generator=g)
     bias0 = score.ln_in.bias.detach().clone()
     sd = dict(full["sd_s"])
+
+    def _setb(v):                                                   # in place THROUGH the parameter: bumps its version -> repack
+        with torch.no_grad():
+            score.ln_in.bias.copy_(v)
+
     try:
         # (a) one massive channel
         b = bias0.clone(); b[123] += 60.0
-        score.ln_in.bias.data.copy_(b); sd["ln_in.bias"] = b.cpu()
+        _setb(b); sd["ln_in.bias"] = b.cpu()
         assert score.can_fold(B, T)
         folded = score.forward_shared_t(x.cuda(), 0.5)
         with torch.no_grad():
@@ -206,7 +211,7 @@ def test_fullsize_lnfold_massive_activation_and_row_offset_guard(full):
         e_a = rel_mse(folded[:nb].cpu(), ref)
         # (b) common offset
         b = bias0 + 6.0
-        score.ln_in.bias.data.copy_(b); sd["ln_in.bias"] = b.cpu()
+        _setb(b); sd["ln_in.bias"] = b.cpu()
         _, mod = score.time_table(torch.tensor([0.5], device="cuda"))
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
@@ -222,6 +227,6 @@ def test_fullsize_lnfold_massive_activation_and_row_offset_guard(full):
               "folding forced %.2e" % (e_a, ratio, e_b, e_forced))
         assert e_a < 1e-4 and e_b < 1e-4
     finally:
-        score.ln_in.bias.data.copy_(bias0)
+        _setb(bias0)
         score._fold_disabled = False
         score.packed()

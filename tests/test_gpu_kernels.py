@@ -494,3 +494,47 @@ def test_resid_ring_epilogue_is_bit_identical_to_plain_loads():
         assert rel_mse(outs[0][0].cpu(), outs[0][3].cpu()) < 1e-12   # producer's x vs the plain residual GEMM's (128^2 kernel at small M)
         ref = x0.double().cpu() + gate.double().cpu() * (a.double().cpu() @ w.double().cpu().T + b.double().cpu())
         assert rel_mse(outs[0][0].cpu(), ref) < 1e-9
+
+
+def test_resid_ring_epilogue_bit_equal_to_register_epilogue(tmp_path):
+    """the XRING epilogue of the one-tile-per-workgroup residual GEMMs (residual rows fetched by LDS-DMA into the idle
+    operand ring, hand-counted `s_waitcnt vmcnt(N)`) must equal the plain register epilogue BIT FOR BIT — a toolchain that
+    emitted one VMEM op more or fewer per pass would read rows before they land.  Same seeded problem (plain RESID_F32 and the
+    LN-fold producer, M = 16,384 x N = 1,024: exactly 256 tiles) in two child processes, LDT_RESID_RING=1 (default) and =0."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    child = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from ldt_amd import ops
+from ldt_amd._lib import EPI_RESID_F32
+g = torch.Generator().manual_seed(11)
+M, D, K = 16384, 1024, 1024
+a = torch.randn(M, K, generator=g).bfloat16().cuda(); w = (torch.randn(D, K, generator=g) / 32).bfloat16().cuda()
+b = torch.randn(D, generator=g).cuda(); gate = torch.randn(1, D, generator=g).cuda(); sc = (0.3 * torch.randn(D, generator=g)).cuda()
+x0 = torch.randn(M, D, generator=g).cuda()
+outs = {}
+for rep in range(3):                      # repeated launches: a latent race would show as run-to-run differences too
+    x1 = x0.clone()
+    ops.gemm_bf16(a, w, b, EPI_RESID_F32, out=x1, resid=x1, gate=gate, gate_sample_stride=0, rows_per_sample=M)
+    x2 = x0.clone()
+    xs, st = ops.gemm_resid_lnstats(a, w, b, x2, sc, gate=gate, gate_sample_stride=0, rows_per_sample=M)
+    cur = dict(x1=x1.cpu(), x2=x2.cpu(), xs=xs.cpu(), st=st.cpu())
+    if outs:
+        assert all(torch.equal(outs[k], cur[k]) for k in cur), "run-to-run difference"
+    outs = cur
+torch.save(outs, sys.argv[1])
+''' % ROOT
+    res = {}
+    for ring in ("1", "0"):
+        out = tmp_path / ("ring%s.pt" % ring)
+        env = dict(os.environ, LDT_RESID_RING=ring)
+        r = subprocess.run([sys.executable, "-c", child, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[ring] = torch.load(out)
+    for k in res["1"]:
+        assert torch.equal(res["1"][k], res["0"][k]), "XRING epilogue differs from the register epilogue in %s" % k
+    ref = res["0"]["x1"]
+    assert bool(torch.isfinite(ref).all()) and float(ref.abs().mean()) > 0.1
