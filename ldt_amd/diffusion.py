@@ -320,20 +320,8 @@ class DiffusionVPSDE:
                 # LangevinCorrector :193-210
                 z = noise[k + 1 + j] if noise is not None else \
                     ops.philox_normal(x.shape, dev, seed, step=i * (1 + ncs) + 1 + j, elem_offset=elem_offset)
-                st = ops.stream_ptr()
-                if n_valid > 0:                                                      # (padding rows of the last rank do not count)
-                    check(lib().ldt_batch_norm_sum(params.data_ptr(), n_valid, per, lv_norms.data_ptr(), lv_sums.data_ptr(), st),
-                          "ldt_batch_norm_sum")
-                    check(lib().ldt_batch_norm_sum(z.data_ptr(), n_valid, per, lv_norms.data_ptr(), lv_sums[1:].data_ptr(), st),
-                          "ldt_batch_norm_sum")
-                else:
-                    lv_sums.zero_()
-                if global_batch is not None:                                         # sharded batch: the path's one cross-sample quantity
-                    from . import dist as ldist
-                    ldist.all_reduce_sum_(lv_sums)
-                check(lib().ldt_langevin_coef(lv_sums.data_ptr(), gb, float(snr), float(std_host[i]), lv_coef.data_ptr(), st),
-                      "ldt_langevin_coef")
-                x = ops.sampler_step(x, params, lv_coef, 0, 1, noise=z, x_mean_out=x_mean)
+                x = langevin_update(x, params, z, x_mean, float(std_host[i]), snr, gb, n_valid, global_batch is not None,
+                                    (lv_coef, lv_sums, lv_norms))
             if traj_list is not None:
                 traj_list.append(x.clone())
             if out_list is not None and (i + 1) % every == 0:
@@ -405,6 +393,26 @@ class DiffusionVPSDE:
                 noise = lincomb((e1, e2, e3, e4), (1.0, 2.0, 2.0, 1.0), 1 / 6)
             x = transfer(x, timesteps[idx * 2 - 1], timesteps[t_next * 2 - 1], noise)               # :304-307
         return x
+
+
+def langevin_update(x, params, z, x_mean, std_t, snr, n_total, n_valid, sharded, scratch):
+    """One LangevinCorrector update (diffusion_continuous.py:193-210) of this rank's rows.  The step size uses BATCH means of
+    per-sample norms — the path's only cross-sample quantity: the two sums are formed over this rank's `n_valid` real rows
+    (the zero-padding rows of the last rank do not count; a rank may hold none), all-reduced when the batch is sharded, and
+    divided by the GLOBAL batch `n_total`.  scratch = (coef[4], sums[2], norms[rows]) device tensors.  Returns the new x
+    (x_mean is written in place)."""
+    lv_coef, lv_sums, lv_norms = scratch
+    per = x[0].numel()
+    if n_valid > 0:
+        ops.batch_norm_sum(params, n_valid, per, lv_norms, lv_sums)
+        ops.batch_norm_sum(z, n_valid, per, lv_norms, lv_sums[1:])
+    else:
+        lv_sums.zero_()
+    if sharded:
+        from . import dist as ldist
+        ldist.all_reduce_sum_(lv_sums)
+    ops.langevin_coef(lv_sums, n_total, snr, std_t, lv_coef)
+    return ops.sampler_step(x, params, lv_coef, 0, 1, noise=z, x_mean_out=x_mean)
 
 
 def _is_stock_score_fn(score_fn):

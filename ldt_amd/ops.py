@@ -180,6 +180,16 @@ def sampler_step(x, params, coef, step, mode=0, noise=None, noise_step_stride=0,
     return x_out
 
 
+def batch_norm_sum(x, n_valid, per_sample, norms_scratch, sum_out):
+    """sum_out[0] = sum over the first n_valid samples of ||x[b]||_2 (LangevinCorrector's torch.norm(...).mean() numerator)."""
+    check(lib().ldt_batch_norm_sum(_p(x), int(n_valid), int(per_sample), _p(norms_scratch), _p(sum_out), stream_ptr()), "ldt_batch_norm_sum")
+
+
+def langevin_coef(sums, n_total, snr, std_t, coef_out):
+    """coef_out[4] = {1, -step/std, sqrt(2 step), 0} from the batch sums {sum ||params_b||, sum ||z_b||} over n_total samples."""
+    check(lib().ldt_langevin_coef(_p(sums), int(n_total), float(snr), float(std_t), _p(coef_out), stream_ptr()), "ldt_langevin_coef")
+
+
 def vpsde_score(params, t, beta0, beta1, sigma2_0):
     """-params / sqrt(var(t)) per sample (Trainer.score_fn, Latent_SDE_Trainer.py:57-61): params fp32 [B, ...], t fp32 [B]."""
     _need(params, torch.float32, "params"); _need(t, torch.float32, "t")

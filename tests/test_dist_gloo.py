@@ -128,3 +128,73 @@ def test_world2_detects_mismatched_generators(tmp_path):
     for r in range(2):
         rec = torch.load(os.path.join(tmp_path, "rank%d.pt" % r), weights_only=False)
         assert rec["err"] is not None and "different x0" in rec["err"] and not rec["calls"]
+
+
+# ---- sharded LangevinCorrector step: the batch-mean norms are the path's one cross-sample quantity ----------------
+def _install_cpu_ops(setter=None):
+    """CPU stand-ins for the four C-ABI wrappers `langevin_update` calls (same arithmetic as csrc/samplers.hip)."""
+    from ldt_amd import ops
+
+    def batch_norm_sum(x, n_valid, per, norms, sum_out):
+        sum_out[0] = x[:n_valid].reshape(n_valid, -1).float().norm(dim=1).sum()
+
+    def langevin_coef(sums, n_total, snr, std_t, coef):
+        grad_norm = (sums[0] / n_total) / std_t
+        noise_norm = sums[1] / n_total
+        step = (snr * noise_norm / grad_norm) ** 2 * 2.0
+        coef[0], coef[1], coef[2], coef[3] = 1.0, -step / std_t, torch.sqrt(step * 2.0), 0.0
+
+    def sampler_step(x, params, coef, step, mode, noise=None, x_mean_out=None, **kw):
+        assert mode == 1
+        xm = coef[0] * x + coef[1] * params
+        if x_mean_out is not None:
+            x_mean_out.copy_(xm)
+        return xm + coef[2] * noise
+
+    setter = setter or (lambda name, fn: setattr(ops, name, fn))
+    for name, fn in (("batch_norm_sum", batch_norm_sum), ("langevin_coef", langevin_coef), ("sampler_step", sampler_step)):
+        setter(name, fn)
+
+
+def _langevin_inputs(B):
+    g = torch.Generator().manual_seed(B)
+    return (torch.randn(B, 8, 12, generator=g), torch.randn(B, 8, 12, generator=g) * 3.0, torch.randn(B, 8, 12, generator=g))
+
+
+def _langevin_rows(x, params, z, lo, per, n_total, sharded):
+    from ldt_amd.diffusion import langevin_update
+    from ldt_amd.trainer import _rows
+    xs, ps, zs = (_rows(t, lo, lo + per, per) for t in (x, params, z))
+    n_valid = max(0, min(per, n_total - lo))
+    xm = torch.empty_like(xs)
+    out = langevin_update(xs, ps, zs, xm, 0.7, 0.16, n_total, n_valid, sharded, (torch.zeros(4), torch.zeros(2), torch.zeros(per)))
+    return out[:n_valid], xm[:n_valid]
+
+
+def _langevin_worker(rank, world, port, B, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _install_cpu_ops()
+        from ldt_amd import dist as ldist
+        lo, hi, per = ldist.shard_bounds(B, rank, world)
+        out, xm = _langevin_rows(*_langevin_inputs(B), lo, per, B, True)
+        torch.save(dict(out=out, xm=xm), os.path.join(out_dir, "lv%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 5, 1])          # even split; last rank padded (3 + 2 real rows); rank 1 holds NO real row
+def test_world2_langevin_step_matches_single_process(tmp_path, monkeypatch, B):
+    sys.path.insert(0, ROOT)
+    from ldt_amd import ops
+    _install_cpu_ops(lambda name, fn: monkeypatch.setattr(ops, name, fn))      # (undone after the test)
+    x, params, z = _langevin_inputs(B)
+    want, want_m = _langevin_rows(x, params, z, 0, B, B, False)
+    port = _free_port()
+    mp.spawn(_langevin_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    parts = [torch.load(os.path.join(tmp_path, "lv%d.pt" % r), weights_only=False) for r in range(2)]
+    got, got_m = torch.cat([p["out"] for p in parts]), torch.cat([p["xm"] for p in parts])
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6) and torch.allclose(got_m, want_m, rtol=1e-6, atol=1e-6)
