@@ -186,6 +186,36 @@ def rel_mse(a, b):
     return float(((a - b) ** 2).sum() / (b ** 2).sum().clamp_min(1e-300))
 
 
+C1_TOL_POINTS, C1_TOL_CHAMFER = 0.55, 0.12
+
+
+def trained_tiny_parity():
+    """End-to-end points / Chamfer at FIXED bars on the well-conditioned fixture tests/golden/trained_tiny.npz: a tiny Score
+    trained by the REFERENCE's own Trainer.update and sampled by the reference's Trainer.sample (oracle/gen_trained_tiny_golden.py),
+    so sampled latents stay at the data scale.  Same check as tests/test_gpu_path.py::test_trainer_sample_trained_weights_fixed_bars."""
+    import json
+    from types import SimpleNamespace
+    import numpy as np
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    gdir = os.path.join(ROOT, "tests", "golden")
+    to_ns = lambda d: SimpleNamespace(**{k: (to_ns(v) if isinstance(v, dict) else v) for k, v in d.items()})
+    cfg = to_ns(json.load(open(os.path.join(gdir, "tiny_cfg.json"))))
+    zf = np.load(os.path.join(gdir, "trained_tiny.npz"))
+    a = {k: torch.from_numpy(np.asarray(zf[k])) for k in zf.files if "::" not in k}
+    sd = {pre: {k.split("::", 1)[1]: torch.from_numpy(np.asarray(zf[k])) for k in zf.files if k.startswith(pre + "::")} for pre in ("w", "c")}
+    score = ldt_amd.Score(cfg.score); score.load_state_dict(sd["w"], strict=True)
+    comp = ldt_amd.Compressor(cfg.compressor); comp.load_state_dict(sd["c"], strict=True)
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    pts, eps = tr.sample(a["x0"].shape[0], x0=a["x0"], noise=a["noises"])
+    cd = float((O.chamfer_cd(pts.cpu(), a["points"]) / (a["points"] ** 2).sum(-1).mean(1)).max())
+    out = {"fixture": "tests/golden/trained_tiny.npz (reference-trained tiny Score, reference-sampled: latents rms %.2f)" % float(a["latent_rms"]),
+           "final_latent": rel_mse(eps.cpu(), a["eps"]), "points_rel_mse": rel_mse(pts.cpu(), a["points"]), "chamfer_norm": cd,
+           "tol": {"final_latent": 1e-4, "points_rel_mse": 1e-3, "chamfer_norm": 1e-3}}
+    out["pass"] = bool(out["final_latent"] <= 1e-4 and out["points_rel_mse"] <= 1e-3 and cd <= 1e-3)
+    return out
+
+
 def c1_baseline_and_parity(trainer, cfg_full):
     """Config C1 EXACTLY (BASELINE.md §3 / SURVEY §8d): B=4, T=256, N=100 ancestral steps + decode.
     The CPU oracle's wall time is the cpu_baseline (x 1/10 for N=1000: the loop body is step-invariant); its trajectory
@@ -231,11 +261,16 @@ def c1_baseline_and_parity(trainer, cfg_full):
               "points_rel_mse": rel_mse(pts.cpu(), ref_pts), "chamfer_norm": cd,
               "decode_conditioning": {"what": "the fp32 oracle's own decode under one bf16 rounding (2^-9 relative) of its latents",
                                       "points_rel_mse": floor_pts, "chamfer_norm": floor_cd},
-              "tol": {"per_step": 1e-4, "final_latent": 1e-4, "chamfer_norm": max(2e-3, 4 * floor_cd),
-                      "points_rel_mse": max(2e-3, 4 * floor_pts), "metric": "relative MSE |a-b|^2/|b|^2; Chamfer / mean squared radius"},
+              # FIXED bars (no bar that moves with the quantity under test).  Latents: the north-star tolerance.  The decoded
+              # cloud of THIS run (random weights: latents inflated to rms ~600, softmaxes saturated) is a robustness number only —
+              # constants = 4x the oracle's own sensitivity to one bf16 rounding as measured in round 2 (0.138 / 0.029); the
+              # well-conditioned Chamfer check is `end_to_end_trained` below.
+              "tol": {"per_step": 1e-4, "final_latent": 1e-4, "chamfer_norm": C1_TOL_CHAMFER, "points_rel_mse": C1_TOL_POINTS,
+                      "metric": "relative MSE |a-b|^2/|b|^2; Chamfer / mean squared radius"},
               "gpu_seconds": round(t_gpu, 3)}
-    parity["pass"] = bool(parity["per_step_max"] <= 1e-4 and parity["final_latent"] <= 1e-4 and cd <= parity["tol"]["chamfer_norm"]
-                          and parity["points_rel_mse"] <= parity["tol"]["points_rel_mse"])
+    parity["end_to_end_trained"] = trained_tiny_parity()
+    parity["pass"] = bool(parity["per_step_max"] <= 1e-4 and parity["final_latent"] <= 1e-4 and cd <= C1_TOL_CHAMFER
+                          and parity["points_rel_mse"] <= C1_TOL_POINTS and parity["end_to_end_trained"]["pass"])
     base = {"value": (B / t_cpu) / 10.0, "unit": "shapes/sec", "cores": cores, "kind": "port",
             "sample": "config C1 exactly: oracle (PyTorch-CPU fp32 restatement of the reference, pinned to reference-captured goldens), "
                       "%d threads, B=%d shapes, T=%d tokens, N=%d ancestral steps + decode = %.1f s wall; x 1/10 for N=1000 "
@@ -343,6 +378,44 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
                              "kind": "port", "sample": "oracle compressor_encode / compressor_decode on %d of the %d clouds" % (nb, batch)}}
 
 
+def vipc_parity(score, tokens, batch, cond, sd_s, n_steps=25, nb=8):
+    """BASELINE configs[4]'s per-GPU share at the production width vs the oracle: a teacher-forced
+    Score.forward(condition=) on the whole batch and `n_steps` free-running steps of the fused conditional loop on injected
+    noise (first `nb` samples compared: trajectories are independent).  Same check as
+    tests/test_gpu_fullsize.py::test_fullsize_vipc_conditioned_vs_oracle."""
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    cfg = ldt_amd.airplane_config(latent_tokens=tokens, sample_N=n_steps)
+    z = cfg.score.z_dim
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(batch, tokens, z, generator=g)
+    t = torch.rand(batch, generator=g) * 0.98 + 0.01
+    pts_tm, img = cond[0].cpu().transpose(1, 2).contiguous(), cond[1].cpu()
+    out = score(x.cuda(), t.cuda(), condition=cond)
+    with torch.no_grad():
+        ref = O.score_forward(sd_s, cfg.score, x, t, condition=(pts_tm, img))
+    torch.manual_seed(4)
+    comp = ldt_amd.Compressor(cfg.compressor); comp.init()
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    x0, noises = O.draw_noises(77, batch, tokens, z, n_steps)
+    traj = []
+    _, eps = tr.sample(batch, condition=cond, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda xx, tt: O.score_forward(sd_s, cfg.score, xx, tt, condition=(pts_tm[:nb], img[:nb])))
+    rec = []
+    with torch.no_grad():
+        ref_eps = O.sample_discrete(sde, fn, x0[:nb], [n[:nb] for n in noises], n_steps, record=rec)
+    xs = traj[0][:, :nb].cpu()
+    curve = [rel_mse(xs[i], rec[i][3]) for i in range(n_steps)]
+    par = {"what": "B=%d, T=%d, S=%d condition tokens, hidden %d x %d blocks: teacher-forced forward (all samples) and %d free-running "
+                   "steps of the fused conditional loop (first %d samples) vs the CPU oracle" % (batch, tokens, cond[0].shape[2], cfg.score.hidden_size,
+                                                                                             cfg.score.num_blocks, n_steps, nb),
+           "teacher_forced": rel_mse(out.cpu(), ref), "per_step_max": max(curve), "final_latent": rel_mse(eps[:nb].cpu(), ref_eps),
+           "tol": 1e-4}
+    par["pass"] = bool(max(par["teacher_forced"], par["per_step_max"], par["final_latent"]) <= 1e-4)
+    return par
+
+
 def extra_sampling(score, tokens, batch, n_steps, vipc, cpu_steps=6):
     """A sampling workload at `tokens` latent tokens: shapes/s of Trainer.sample(batch) with n_steps SDE steps (+ decode), its
     whole-job MFMA fraction, and a bounded CPU-oracle baseline (B=4, first `cpu_steps` steps, extrapolated linearly)."""
@@ -376,7 +449,9 @@ def extra_sampling(score, tokens, batch, n_steps, vipc, cpu_steps=6):
         t0 = time.time()
         O.sample_discrete(sde, fn, x0, noises, n_steps, max_steps=cpu_steps)
         t_step = (time.time() - t0) / cpu_steps
-    return {"shapes_per_s": round(batch / dt, 3), "ms_per_sde_step": round(1e3 * dt / n_steps, 3), "seconds_per_call": round(dt, 3),
+    par = vipc_parity(score, tokens, batch, cond, sd_s) if vipc else None
+    return {**({"parity": par} if par else {}),
+            "shapes_per_s": round(batch / dt, 3), "ms_per_sde_step": round(1e3 * dt / n_steps, 3), "seconds_per_call": round(dt, 3),
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                          "scope": "whole job (Score flops of SURVEY §8d / wall time)"},
             "cpu_baseline": {"value": Bc / (n_steps * t_step), "unit": "shapes/sec", "cores": host_cores(), "kind": "port",
