@@ -143,7 +143,7 @@ def test_gemm_lnfold_error_law_vs_row_mean(ratio):
     if ratio <= 4.0:
         assert e_fold < 1e-4
     mon = ops.fold_mean_ratio(stats, D)
-    assert abs(mon - ratio ** 2) < 0.15 * ratio ** 2 + 0.05, mon
+    assert 0.85 * ratio ** 2 <= mon <= 1.5 * ratio ** 2 + 0.05, mon      # (the MAX over 512 rows of a 1024-sample estimate)
 
 
 def test_gemm_lnfold_rejects_bad_shapes():

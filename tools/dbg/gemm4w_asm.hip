@@ -1,0 +1,268 @@
+// EXPERIMENT (tools/dbg, not part of the product): the vendor library's tiling for this chip — 256x256 tile, FOUR waves
+// (one per SIMD), 128x128 per wave = 8x8 accumulator tiles of v_mfma_f32_16x16x32_bf16 in 256 AGPRs — with a HAND-PLACED
+// instruction stream: every MFMA, ds_read_b128 and LDS-DMA of the main loop is an `asm volatile` statement, so program order
+// is the source order (hipcc only allocates registers).  Round 2's compiler-scheduled attempt (gemm4w_exp.hip) spent 15
+// v_accvgpr moves per MFMA shuffling accumulators; here the accumulators are tied in place ("+a").
+//
+//   * K in 32-deep sub-tiles through a 4-slot LDS ring (32 KiB per slot: X[256][32] | W[256][32], rows of 64 B, 16-B chunk
+//     XOR-swizzled by row as in the product kernel).  Sub-tile g's operands sit in VGPRs (two fragment sets) while its slot is
+//     already being refilled: iteration g = [vmcnt(16); s_barrier; 64 MFMAs on set g&1, between them 16 ds_reads of sub-tile
+//     g+1 into the other set and 8 LDS-DMA pieces of sub-tile g+4 into slot g&3; lgkmcnt(0)].
+//   * At most one filler per MFMA gap (an MFMA holds the issue port for 8 of its 16 cycles), M0 set-up and the DMA itself in
+//     different gaps, and the four waves' DMA gaps interleaved (wave w uses gaps 2w, 2w+1 of every 8-MFMA group) so that the
+//     CU's address pipeline sees one request every 32 cycles instead of four at once.
+//   * Persistent over tiles; the operand stream runs across tile boundaries (the next tile's first four sub-tiles are requested
+//     during the last iterations of the current one).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dbg/gemm4w_asm.hip -o /tmp/gemm4w_asm && /tmp/gemm4w_asm [M N K] [store]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <utility>
+#include <vector>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define STAGE_BYTES 32768
+#define OPER_BYTES 16384
+#ifndef STAGGER
+#define STAGGER 1
+#endif
+#ifndef SPLIT_M0
+#define SPLIT_M0 1          // 1: M0 set-up and the DMA in different MFMA gaps; 0: one statement (s_add m0; s_nop 0; DMA)
+#endif
+
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+struct Args { const bf16_t* X; const bf16_t* W; bf16_t* Y; int M, N, K; int store; };
+
+struct Ctx {
+    f32x4 acc[8][8];
+    i32x4 xf[2][8], wf[2][8];
+    int xrd[2], wrd[2];               // per-lane LDS read bases for slots {0,1} / {2,3}
+    const char* xptr[4];              // per-lane DMA sources of this wave's 4 X pieces / 4 W pieces (current 4-block of the stream)
+    const char* wptr[4];
+    int wbase;                        // wave-uniform: LDS base + wave * 4096
+};
+
+template <int IMM>
+__device__ __forceinline__ void set_m0(int wbase) { asm volatile("s_add_u32 m0, %0, %1" ::"s"(wbase), "i"(IMM) : "scc"); }
+template <int KOFF>
+__device__ __forceinline__ void glds(const char* p) { asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(p), "i"(KOFF) : "memory"); }
+template <int IMM, int KOFF>
+__device__ __forceinline__ void glds_m0(const char* p, int wbase) {
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%3" ::"v"(p), "s"(wbase), "i"(IMM), "i"(KOFF) : "memory", "scc");
+}
+template <int OFF>
+__device__ __forceinline__ void dsread(i32x4& dst, int addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF)); }
+
+// MFMA number T (0..63) of sub-tile G and the filler of the gap behind it
+template <int WV, int G, int T>
+__device__ __forceinline__ void gap(Ctx& c) {
+    constexpr int P = G & 1, Q = P ^ 1;
+    constexpr int k = T >> 3, p = T & 7;
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c.acc[k][p]) : "v"(c.wf[P][k]), "v"(c.xf[P][p]));
+    constexpr int RS = (G + 1) & 3;                                   // slot read this iteration (sub-tile g+1)
+    constexpr int ROFF = (RS & 1) * STAGE_BYTES;
+    constexpr int RH = RS >> 1;
+    constexpr int DCONST = G * STAGE_BYTES + (k < 4 ? k * 1024 : OPER_BYTES + (k - 4) * 1024);   // DMA piece k of sub-tile g+4 -> slot g&3
+    constexpr int KOFF = G * 64;
+    constexpr int PG = STAGGER ? 2 * WV + 1 : 1;                      // gap of the LDS-DMA inside a group of 8
+    constexpr int PS = PG - 1;                                        // gap of its M0 set-up
+    // (the instruction's immediate offset is added to the global AND the LDS address: M0 carries destination - KOFF)
+    if constexpr (p == PS) {
+        if constexpr (SPLIT_M0) set_m0<DCONST - KOFF>(c.wbase);
+    } else if constexpr (p == PG) {
+        if constexpr (SPLIT_M0) { if constexpr (k < 4) glds<KOFF>(c.xptr[k]); else glds<KOFF>(c.wptr[k - 4]); }
+        else { if constexpr (k < 4) glds_m0<DCONST - KOFF, KOFF>(c.xptr[k], c.wbase); else glds_m0<DCONST - KOFF, KOFF>(c.wptr[k - 4], c.wbase); }
+    } else {
+        // reads: three per group in groups 0..4, one in group 5; order w0, x0..x7, w1..w7 (first needed first)
+        constexpr int fp = (p - PG - 1 + 8) & 7;                      // 0..5 among this group's free gaps
+        constexpr int sl = (fp == 0) ? 0 : (fp == 2) ? 1 : (fp == 4) ? 2 : -1;
+        if constexpr (sl >= 0 && (k < 5 || (k == 5 && sl == 0))) {
+            constexpr int r = k * 3 + sl;                             // 0..15
+            if constexpr (r == 0) dsread<ROFF + OPER_BYTES>(c.wf[Q][0], c.wrd[RH]);
+            else if constexpr (r <= 8) dsread<ROFF + (r - 1) * 1024>(c.xf[Q][r - 1], c.xrd[RH]);
+            else dsread<ROFF + OPER_BYTES + (r - 8) * 1024>(c.wf[Q][r - 8], c.wrd[RH]);
+        }
+    }
+}
+
+template <int WV, int G, int... Ts>
+__device__ __forceinline__ void subtile(Ctx& c, std::integer_sequence<int, Ts...>) {
+    constexpr int Q = (G & 1) ^ 1;
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    (gap<WV, G, Ts>(c), ...);
+    // the other fragment set is complete before the next iteration's first MFMA; "+v" ties the registers through the wait
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(c.xf[Q][0]), "+v"(c.xf[Q][1]), "+v"(c.xf[Q][2]), "+v"(c.xf[Q][3]), "+v"(c.xf[Q][4]), "+v"(c.xf[Q][5]), "+v"(c.xf[Q][6]),
+                   "+v"(c.xf[Q][7]), "+v"(c.wf[Q][0]), "+v"(c.wf[Q][1]), "+v"(c.wf[Q][2]), "+v"(c.wf[Q][3]), "+v"(c.wf[Q][4]), "+v"(c.wf[Q][5]),
+                   "+v"(c.wf[Q][6]), "+v"(c.wf[Q][7]));
+}
+
+template <int G, int PIECE>
+__device__ __forceinline__ void prologue_piece(Ctx& c) {
+    constexpr int DCONST = G * STAGE_BYTES + (PIECE < 4 ? PIECE * 1024 : OPER_BYTES + (PIECE - 4) * 1024);
+    if constexpr (PIECE < 4) glds_m0<DCONST - G * 64, G * 64>(c.xptr[PIECE], c.wbase);
+    else glds_m0<DCONST - G * 64, G * 64>(c.wptr[PIECE - 4], c.wbase);
+}
+template <int... Is>
+__device__ __forceinline__ void prologue(Ctx& c, std::integer_sequence<int, Is...>) { (prologue_piece<(Is >> 3), (Is & 7)>(c), ...); }
+template <int... Is>
+__device__ __forceinline__ void first_reads(Ctx& c, std::integer_sequence<int, Is...>) {
+    (dsread<Is * 1024>(c.xf[0][Is], c.xrd[0]), ...);
+    (dsread<OPER_BYTES + Is * 1024>(c.wf[0][Is], c.wrd[0]), ...);
+}
+
+template <int WV>
+__device__ __forceinline__ void run(const Args& a, char* smem, const int wave, const int lane) {
+    Ctx c;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, lchk = lane >> 4;
+    const int nks = a.K >> 5;
+    const int tiles_n = a.N / 256;
+    const int tiles = (a.M / 256) * tiles_n;
+    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    // fragment i of X = rows wm*128 + i*16 + lrow: the swizzle term depends on lrow only -> "+ i*1024" immediates
+    const int rx = wm * 128 + lrow, rw = wn * 128 + lrow;
+    const int smem_base = (int)(size_t)smem;
+    c.xrd[0] = smem_base + rx * 64 + ((lchk ^ swz(rx)) << 4);
+    c.wrd[0] = smem_base + rw * 64 + ((lchk ^ swz(rw)) << 4);
+    c.xrd[1] = c.xrd[0] + 2 * STAGE_BYTES;
+    c.wrd[1] = c.wrd[0] + 2 * STAGE_BYTES;
+    c.wbase = __builtin_amdgcn_readfirstlane(smem_base + wave * 4096);
+
+    int dtile = 0, dpos = 0;
+    auto seek = [&](int it) {
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+        const int tt = tile < tiles ? tile : tiles - 1;              // past the end: re-read the last tile (never consumed)
+        const int m0 = (tt / tiles_n) * 256, n0 = (tt % tiles_n) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (wave * 4 + q) * 16 + (lane >> 2);
+            const int cs = (lane & 3) ^ swz(r);
+            c.xptr[q] = reinterpret_cast<const char*>(a.X + (long)(m0 + r) * a.K + cs * 8);
+            c.wptr[q] = reinterpret_cast<const char*>(a.W + (long)(n0 + r) * a.K + cs * 8);
+        }
+    };
+    auto advance = [&]() {                                             // after the DMAs of a 4-block of the stream
+        dpos += 4;
+        if (dpos == nks) { dpos = 0; ++dtile; seek(dtile); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c.xptr[q] += 256; c.wptr[q] += 256; }
+        }
+    };
+    seek(0);
+    prologue(c, std::make_integer_sequence<int, 32>{});               // sub-tiles 0..3 of the first tile -> slots 0..3
+    advance();
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");  // sub-tile 0 landed everywhere
+    first_reads(c, std::make_integer_sequence<int, 8>{});
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(c.xf[0][0]), "+v"(c.xf[0][1]), "+v"(c.xf[0][2]), "+v"(c.xf[0][3]), "+v"(c.xf[0][4]), "+v"(c.xf[0][5]), "+v"(c.xf[0][6]),
+                   "+v"(c.xf[0][7]), "+v"(c.wf[0][0]), "+v"(c.wf[0][1]), "+v"(c.wf[0][2]), "+v"(c.wf[0][3]), "+v"(c.wf[0][4]), "+v"(c.wf[0][5]),
+                   "+v"(c.wf[0][6]), "+v"(c.wf[0][7]));
+
+    using Seq = std::make_integer_sequence<int, 64>;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+        const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c.acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 4" ::: "memory");                         // compiler-written accumulators -> first MFMA (hipcc pads nothing for an asm)
+        for (int g4 = 0; g4 < nks; g4 += 4) {
+            subtile<WV, 0>(c, Seq{});
+            subtile<WV, 1>(c, Seq{});
+            subtile<WV, 2>(c, Seq{});
+            subtile<WV, 3>(c, Seq{});
+            advance();
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMAs' results -> compiler-generated readers
+        if (a.store) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = m0 + wm * 128 + mi * 16 + lrow;
+#pragma unroll
+                for (int nj = 0; nj < 8; ++nj) {
+                    const int n = n0 + wn * 128 + nj * 16 + lchk * 4;
+                    const f32x4 v = c.acc[nj][mi];
+                    const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    *reinterpret_cast<bf16x4*>(a.Y + (long)m * a.N + n) = pk;
+                }
+            }
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += c.acc[i][j][0] + c.acc[i][j][1] + c.acc[i][j][2] + c.acc[i][j][3];
+            if (s == 123.456f) a.Y[threadIdx.x] = (bf16_t)s;         // keeps the accumulators live, never true in practice
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void gemm4w_asm_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: run<0>(a, smem, wave, lane); break;
+        case 1: run<1>(a, smem, wave, lane); break;
+        case 2: run<2>(a, smem, wave, lane); break;
+        default: run<3>(a, smem, wave, lane); break;
+    }
+}
+
+static float bf2f(bf16_t v) { return (float)v; }
+
+int main(int argc, char** argv) {
+    int M = argc > 3 ? atoi(argv[1]) : 16384, N = argc > 3 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 1024;
+    int store = argc > 4 ? atoi(argv[4]) : 0;
+    if (M % 256 || N % 256 || K % 128) { printf("M, N multiples of 256; K multiple of 128\n"); return 1; }
+    const size_t pad = 1 << 20;                                       // the tail of the stream re-reads the last tile: no overrun, pad anyway
+    std::vector<bf16_t> hx((size_t)M * K), hw((size_t)N * K);
+    srand(1);
+    for (auto& v : hx) v = (bf16_t)((rand() % 2001 - 1000) / 1000.0f);
+    for (auto& v : hw) v = (bf16_t)((rand() % 2001 - 1000) / 1000.0f / sqrtf((float)K));
+    bf16_t *dx, *dw, *dy;
+    hipMalloc(&dx, hx.size() * 2 + pad); hipMalloc(&dw, hw.size() * 2 + pad); hipMalloc(&dy, (size_t)M * N * 2);
+    hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(dy, 0, (size_t)M * N * 2);
+    Args a{dx, dw, dy, M, N, K, 1};
+    const int lds = 4 * STAGE_BYTES;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int tiles = (M / 256) * (N / 256), grid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(gemm4w_asm_kernel, dim3(grid), dim3(256), lds, 0, a);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 2; }
+    std::vector<bf16_t> hy((size_t)M * N);
+    hipMemcpy(hy.data(), dy, hy.size() * 2, hipMemcpyDeviceToHost);
+    double maxerr = 0;
+    for (int t = 0; t < 20000; ++t) {
+        const int m = rand() % M, n = rand() % N;
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)bf2f(hx[(size_t)m * K + k]) * bf2f(hw[(size_t)n * K + k]);
+        const double e = fabs(ref - bf2f(hy[(size_t)m * N + n]));
+        if (e > maxerr) maxerr = e;
+    }
+    printf("check: max abs err over 20000 samples %.4g (bf16 out, |y| ~ 0.5)\n", maxerr);
+    a.store = store;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(gemm4w_asm_kernel, dim3(grid), dim3(256), lds, 0, a);
+    hipEventRecord(e0);
+    const int reps = 30;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(gemm4w_asm_kernel, dim3(grid), dim3(256), lds, 0, a);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("gemm4w_asm M=%d N=%d K=%d store=%d stagger=%d split_m0=%d: %.1f us  %.0f TFLOP/s\n", M, N, K, store, STAGGER, SPLIT_M0, ms * 1e3,
+           2.0 * M * N * K / ms / 1e9);
+    return maxerr < 0.02 ? 0 : 3;
+}
