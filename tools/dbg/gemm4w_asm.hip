@@ -33,6 +33,36 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef STAGGER
 #define STAGGER 1
 #endif
+#ifndef NO_DMA
+#define NO_DMA 0            // ablation: no LDS-DMA in the loop (operands go stale: timing only)
+#endif
+#ifndef NO_READ
+#define NO_READ 0           // ablation: no ds_reads in the loop
+#endif
+#ifndef NO_BARRIER
+#define NO_BARRIER 0        // ablation: no s_barrier / vmcnt wait at the top of a sub-tile
+#endif
+#ifndef NO_MFMA
+#define NO_MFMA 0           // ablation: no MFMAs (what the loads + reads + barriers cost alone)
+#endif
+#ifndef FULL_LINE
+#define FULL_LINE 0         // timing-only (with NO_MFMA): DMA pieces of 8 rows x 128 B instead of 16 rows x 64 B, same bytes per sub-tile
+#endif
+#ifndef DMA_MODE
+#define DMA_MODE 0          // 0: global_load_lds_dwordx4 with per-lane 64-bit pointers; 1: buffer_load_dwordx4 ... offen lds (SRD + 32-bit offsets)
+#endif
+#ifndef CACHE
+#define CACHE 0             // buffer_load cache policy: 0 none, 1 nt, 2 sc0 sc1, 3 sc1
+#endif
+#if CACHE == 1
+#define CPOL " nt"
+#elif CACHE == 2
+#define CPOL " sc0 sc1"
+#elif CACHE == 3
+#define CPOL " sc1"
+#else
+#define CPOL ""
+#endif
 #ifndef SPLIT_M0
 #define SPLIT_M0 1          // 1: M0 set-up and the DMA in different MFMA gaps; 0: one statement (s_add m0; s_nop 0; DMA)
 #endif
@@ -48,6 +78,8 @@ struct Ctx {
     const char* xptr[4];              // per-lane DMA sources of this wave's 4 X pieces / 4 W pieces (current 4-block of the stream)
     const char* wptr[4];
     int wbase;                        // wave-uniform: LDS base + wave * 4096
+    i32x4 xsrd, wsrd;                 // DMA_MODE 1: buffer descriptors of the current X / W row panel at the stream's 4-block
+    int xvo[4], wvo[4];               //             per-lane byte offsets of the 4 pieces (constant)
 };
 
 template <int IMM>
@@ -58,6 +90,15 @@ template <int IMM, int KOFF>
 __device__ __forceinline__ void glds_m0(const char* p, int wbase) {
     asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%3" ::"v"(p), "s"(wbase), "i"(IMM), "i"(KOFF) : "memory", "scc");
 }
+template <int KOFF>
+__device__ __forceinline__ void bload(int voff, i32x4 srd) {
+    asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%2" CPOL " lds" ::"v"(voff), "s"(srd), "i"(KOFF) : "memory");
+}
+template <int IMM, int KOFF>
+__device__ __forceinline__ void bload_m0(int voff, i32x4 srd, int wbase) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, 0 offen offset:%4" CPOL " lds" ::"v"(voff), "s"(srd), "s"(wbase), "i"(IMM),
+                 "i"(KOFF) : "memory", "scc");
+}
 template <int OFF>
 __device__ __forceinline__ void dsread(i32x4& dst, int addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF)); }
 
@@ -66,25 +107,33 @@ template <int WV, int G, int T>
 __device__ __forceinline__ void gap(Ctx& c) {
     constexpr int P = G & 1, Q = P ^ 1;
     constexpr int k = T >> 3, p = T & 7;
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c.acc[k][p]) : "v"(c.wf[P][k]), "v"(c.xf[P][p]));
+    if constexpr (!NO_MFMA) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c.acc[k][p]) : "v"(c.wf[P][k]), "v"(c.xf[P][p]));
     constexpr int RS = (G + 1) & 3;                                   // slot read this iteration (sub-tile g+1)
     constexpr int ROFF = (RS & 1) * STAGE_BYTES;
     constexpr int RH = RS >> 1;
     constexpr int DCONST = G * STAGE_BYTES + (k < 4 ? k * 1024 : OPER_BYTES + (k - 4) * 1024);   // DMA piece k of sub-tile g+4 -> slot g&3
-    constexpr int KOFF = G * 64;
+    constexpr int KOFF = G * (FULL_LINE ? 128 : 64);
     constexpr int PG = STAGGER ? 2 * WV + 1 : 1;                      // gap of the LDS-DMA inside a group of 8
     constexpr int PS = PG - 1;                                        // gap of its M0 set-up
     // (the instruction's immediate offset is added to the global AND the LDS address: M0 carries destination - KOFF)
     if constexpr (p == PS) {
-        if constexpr (SPLIT_M0) set_m0<DCONST - KOFF>(c.wbase);
+        if constexpr (DMA_MODE == 1 && G == 0 && (k == 0 || k == 4)) {}
+        else if constexpr ((SPLIT_M0 || DMA_MODE == 1) && !NO_DMA) set_m0<DCONST - KOFF>(c.wbase);
     } else if constexpr (p == PG) {
-        if constexpr (SPLIT_M0) { if constexpr (k < 4) glds<KOFF>(c.xptr[k]); else glds<KOFF>(c.wptr[k - 4]); }
+        if constexpr (NO_DMA) {}
+        else if constexpr (DMA_MODE == 1) {
+            // (first piece of a 4-block: the descriptor was just advanced by compiler-placed SALU code -> s_nop 4 inside the statement)
+            if constexpr (G == 0 && k == 0) bload_m0<DCONST - KOFF, KOFF>(c.xvo[0], c.xsrd, c.wbase);
+            else if constexpr (k < 4) bload<KOFF>(c.xvo[k], c.xsrd);
+            else if constexpr (G == 0 && k == 4) bload_m0<DCONST - KOFF, KOFF>(c.wvo[0], c.wsrd, c.wbase);
+            else bload<KOFF>(c.wvo[k - 4], c.wsrd);
+        } else if constexpr (SPLIT_M0) { if constexpr (k < 4) glds<KOFF>(c.xptr[k]); else glds<KOFF>(c.wptr[k - 4]); }
         else { if constexpr (k < 4) glds_m0<DCONST - KOFF, KOFF>(c.xptr[k], c.wbase); else glds_m0<DCONST - KOFF, KOFF>(c.wptr[k - 4], c.wbase); }
     } else {
         // reads: three per group in groups 0..4, one in group 5; order w0, x0..x7, w1..w7 (first needed first)
         constexpr int fp = (p - PG - 1 + 8) & 7;                      // 0..5 among this group's free gaps
         constexpr int sl = (fp == 0) ? 0 : (fp == 2) ? 1 : (fp == 4) ? 2 : -1;
-        if constexpr (sl >= 0 && (k < 5 || (k == 5 && sl == 0))) {
+        if constexpr (!NO_READ && sl >= 0 && (k < 5 || (k == 5 && sl == 0))) {
             constexpr int r = k * 3 + sl;                             // 0..15
             if constexpr (r == 0) dsread<ROFF + OPER_BYTES>(c.wf[Q][0], c.wrd[RH]);
             else if constexpr (r <= 8) dsread<ROFF + (r - 1) * 1024>(c.xf[Q][r - 1], c.xrd[RH]);
@@ -96,7 +145,7 @@ __device__ __forceinline__ void gap(Ctx& c) {
 template <int WV, int G, int... Ts>
 __device__ __forceinline__ void subtile(Ctx& c, std::integer_sequence<int, Ts...>) {
     constexpr int Q = (G & 1) ^ 1;
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    if constexpr (!NO_BARRIER) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     (gap<WV, G, Ts>(c), ...);
     // the other fragment set is complete before the next iteration's first MFMA; "+v" ties the registers through the wait
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -108,8 +157,12 @@ __device__ __forceinline__ void subtile(Ctx& c, std::integer_sequence<int, Ts...
 template <int G, int PIECE>
 __device__ __forceinline__ void prologue_piece(Ctx& c) {
     constexpr int DCONST = G * STAGE_BYTES + (PIECE < 4 ? PIECE * 1024 : OPER_BYTES + (PIECE - 4) * 1024);
-    if constexpr (PIECE < 4) glds_m0<DCONST - G * 64, G * 64>(c.xptr[PIECE], c.wbase);
-    else glds_m0<DCONST - G * 64, G * 64>(c.wptr[PIECE - 4], c.wbase);
+    constexpr int KO = G * (FULL_LINE ? 128 : 64);
+    if constexpr (DMA_MODE == 1) {
+        if constexpr (PIECE < 4) bload_m0<DCONST - KO, KO>(c.xvo[PIECE], c.xsrd, c.wbase);
+        else bload_m0<DCONST - KO, KO>(c.wvo[PIECE - 4], c.wsrd, c.wbase);
+    } else if constexpr (PIECE < 4) glds_m0<DCONST - KO, KO>(c.xptr[PIECE], c.wbase);
+    else glds_m0<DCONST - KO, KO>(c.wptr[PIECE - 4], c.wbase);
 }
 template <int... Is>
 __device__ __forceinline__ void prologue(Ctx& c, std::integer_sequence<int, Is...>) { (prologue_piece<(Is >> 3), (Is & 7)>(c), ...); }
@@ -124,11 +177,17 @@ __device__ __forceinline__ void run(const Args& a, char* smem, const int wave, c
     Ctx c;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 15, lchk = lane >> 4;
-    const int nks = a.K >> 5;
+    const int nks = a.K >> 5;                                         // (FULL_LINE: half the rows, twice the k per sub-tile: the stream runs into the next rows — timing only)
     const int tiles_n = a.N / 256;
     const int tiles = (a.M / 256) * tiles_n;
-    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // tiles cut into 8 contiguous chunks, one per XCD label (blockIdx % 8): the column tiles of an X row panel share an L2
+    const int G_ = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int nx = G_ < 8 ? G_ : 8, xcd = bid % nx, jb = bid / nx;
+    const int wpx = (G_ - xcd + nx - 1) / nx;
+    const int c_lo = (int)((long)tiles * xcd / nx), c_hi = (int)((long)tiles * (xcd + 1) / nx);
+    const int my_tiles = (c_hi - c_lo - jb + wpx - 1) / wpx > 0 ? (c_hi - c_lo - jb + wpx - 1) / wpx : 0;
     if (my_tiles <= 0) return;
+    auto tile_id = [&](int it) { const int t = c_lo + jb + it * wpx; return t < c_hi ? t : c_hi - 1; };
     // fragment i of X = rows wm*128 + i*16 + lrow: the swizzle term depends on lrow only -> "+ i*1024" immediates
     const int rx = wm * 128 + lrow, rw = wn * 128 + lrow;
     const int smem_base = (int)(size_t)smem;
@@ -140,23 +199,31 @@ __device__ __forceinline__ void run(const Args& a, char* smem, const int wave, c
 
     int dtile = 0, dpos = 0;
     auto seek = [&](int it) {
-        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-        const int tt = tile < tiles ? tile : tiles - 1;              // past the end: re-read the last tile (never consumed)
+        const int tt = tile_id(it);                                   // past the end: re-read the last tile (never consumed)
         const int m0 = (tt / tiles_n) * 256, n0 = (tt % tiles_n) * 256;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = (wave * 4 + q) * 16 + (lane >> 2);
-            const int cs = (lane & 3) ^ swz(r);
+            const int r = FULL_LINE ? (wave * 4 + q) * 8 + (lane >> 3) : (wave * 4 + q) * 16 + (lane >> 2);
+            const int cs = FULL_LINE ? (lane & 7) : (lane & 3) ^ swz(r);
             c.xptr[q] = reinterpret_cast<const char*>(a.X + (long)(m0 + r) * a.K + cs * 8);
             c.wptr[q] = reinterpret_cast<const char*>(a.W + (long)(n0 + r) * a.K + cs * 8);
+            c.xvo[q] = r * a.K * 2 + cs * 16;
+            c.wvo[q] = c.xvo[q];
         }
+        const unsigned long xb = reinterpret_cast<unsigned long>(a.X + (long)m0 * a.K), wb = reinterpret_cast<unsigned long>(a.W + (long)n0 * a.K);
+        c.xsrd = (i32x4){(int)(unsigned)xb, (int)(unsigned)(xb >> 32), -1, 0x00020000};
+        c.wsrd = (i32x4){(int)(unsigned)wb, (int)(unsigned)(wb >> 32), -1, 0x00020000};
     };
     auto advance = [&]() {                                             // after the DMAs of a 4-block of the stream
         dpos += 4;
         if (dpos == nks) { dpos = 0; ++dtile; seek(dtile); }
         else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { c.xptr[q] += 256; c.wptr[q] += 256; }
+            for (int q = 0; q < 4; ++q) { c.xptr[q] += FULL_LINE ? 512 : 256; c.wptr[q] += FULL_LINE ? 512 : 256; }
+            unsigned long xb = ((unsigned long)(unsigned)c.xsrd[1] << 32 | (unsigned)c.xsrd[0]) + 256;
+            unsigned long wb = ((unsigned long)(unsigned)c.wsrd[1] << 32 | (unsigned)c.wsrd[0]) + 256;
+            c.xsrd[0] = (int)(unsigned)xb; c.xsrd[1] = (int)(unsigned)(xb >> 32);
+            c.wsrd[0] = (int)(unsigned)wb; c.wsrd[1] = (int)(unsigned)(wb >> 32);
         }
     };
     seek(0);
@@ -171,7 +238,7 @@ __device__ __forceinline__ void run(const Args& a, char* smem, const int wave, c
 
     using Seq = std::make_integer_sequence<int, 64>;
     for (int it = 0; it < my_tiles; ++it) {
-        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+        const int tile = tile_id(it);
         const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -262,7 +329,8 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(gemm4w_asm_kernel, dim3(grid), dim3(256), lds, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-    printf("gemm4w_asm M=%d N=%d K=%d store=%d stagger=%d split_m0=%d: %.1f us  %.0f TFLOP/s\n", M, N, K, store, STAGGER, SPLIT_M0, ms * 1e3,
+    printf("gemm4w_asm M=%d N=%d K=%d store=%d dma_mode=%d full_line=%d cache='%s' no_dma=%d no_read=%d no_barrier=%d no_mfma=%d: %.1f us  %.0f TFLOP/s\n", M, N, K, store,
+           DMA_MODE, FULL_LINE, CPOL, NO_DMA, NO_READ, NO_BARRIER, NO_MFMA, ms * 1e3,
            2.0 * M * N * K / ms / 1e9);
-    return maxerr < 0.02 ? 0 : 3;
+    return (maxerr < 0.02 || NO_DMA || NO_READ || NO_BARRIER || NO_MFMA) ? 0 : 3;
 }
