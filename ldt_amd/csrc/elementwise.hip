@@ -39,17 +39,39 @@ int ldt_cast_pad_launch(const float* src, long lds, bf16_t* dst, long ldd, long 
 //   reference: tools/utils.py:127-133 (LayerNorm wrapper), model/layers.py:136-137 (modulate), :218-219 (use)
 // One wave per row; shift/scale are per-sample vectors (stride 0 = shared by the batch, the
 // unconditional sampler's case: SURVEY hard part 3) selected by a device-side step counter.
-template <int NV>   // NV float4 chunks per lane: C = NV*256
+template <int NV, bool RESID = false>   // NV float4 chunks per lane: C = NV*256; RESID: residual + split-K reduction first (LnArgs.part)
 __global__ __launch_bounds__(256) void ln_mod_vec_kernel(const LnArgs a) {
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const float* xr = a.x + row * a.ldx;
+    const long modoff = (a.shift || a.part) ? (a.step_ptr ? (long)(*a.step_ptr) * a.mod_step_stride : 0) + (row / a.rows_per_sample) * a.mod_sample_stride : 0;
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(xr + i * 256 + lane * 4);
+        const int c = i * 256 + lane * 4;
+        v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+        if (RESID) {
+            // x <- x + gate * (sum_s part[s] + bias): the residual update of layers.py:218-219 with the split-K partials of the GEMM that
+            // precedes this LayerNorm summed in the fixed order s = 0, 1, ... (deterministic), written back in place
+            f32x4 acc = *reinterpret_cast<const f32x4*>(a.part + row * (long)a.C + c);
+            for (int sp = 1; sp < a.nparts; ++sp) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(a.part + sp * a.part_stride + row * (long)a.C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += t[j];
+            }
+            if (a.pbias) { const f32x4 b = *reinterpret_cast<const f32x4*>(a.pbias + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += b[j]; }
+            if (a.gate) { const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + modoff + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = v[i][j] + g[j] * acc[j]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = v[i][j] + acc[j]; }
+            *reinterpret_cast<f32x4*>(a.x_out + row * a.ldx + c) = v[i];
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)a.C;
@@ -60,11 +82,7 @@ __global__ __launch_bounds__(256) void ln_mod_vec_kernel(const LnArgs a) {
         for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
     const float rstd = rsqrtf(wave_sum(q) / (float)a.C + 1e-6f);
     const float* sh = a.shift; const float* sc = a.scale;
-    if (sh) {
-        const long off = (a.step_ptr ? (long)(*a.step_ptr) * a.mod_step_stride : 0) +
-                         (row / a.rows_per_sample) * a.mod_sample_stride;
-        sh += off; sc += off;
-    }
+    if (sh) { sh += modoff; sc += modoff; }
     bf16_t* yr = a.y + row * a.ldy;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -119,6 +137,18 @@ int ldt_ln_launch(const LnArgs* a, hipStream_t s) {
     const bool vec = (a->C % 256 == 0) && a->C <= 1024 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && ldt_aligned16(a->x) &&
                      (reinterpret_cast<uintptr_t>(a->y) & 7) == 0 && (!a->shift || (ldt_aligned16(a->shift) && ldt_aligned16(a->scale) &&
                      a->mod_sample_stride % 4 == 0 && a->mod_step_stride % 4 == 0)) && (!a->w || (ldt_aligned16(a->w) && ldt_aligned16(a->b)));
+    if (a->part) {
+        LDT_REQUIRE(vec && a->nparts >= 1 && a->x_out && a->ldx == a->C && a->rows_per_sample > 0 && ldt_aligned16(a->part) && a->part_stride % 4 == 0 &&
+                    (!a->pbias || ldt_aligned16(a->pbias)) && (!a->gate || ldt_aligned16(a->gate)), LDT_EARG,
+                    "ln: the residual / split-K form needs the vector path (C %% 256 == 0 <= 1024, dense rows) and aligned operands");
+        switch (a->C / 256) {
+            case 1: hipLaunchKernelGGL((ln_mod_vec_kernel<1, true>), grid, block, 0, s, *a); break;
+            case 2: hipLaunchKernelGGL((ln_mod_vec_kernel<2, true>), grid, block, 0, s, *a); break;
+            case 3: hipLaunchKernelGGL((ln_mod_vec_kernel<3, true>), grid, block, 0, s, *a); break;
+            default: hipLaunchKernelGGL((ln_mod_vec_kernel<4, true>), grid, block, 0, s, *a); break;
+        }
+        return ldt_check_launch("ln_modulate(resid)");
+    }
     if (vec) {
         switch (a->C / 256) {
             case 1: hipLaunchKernelGGL(ln_mod_vec_kernel<1>, grid, block, 0, s, *a); break;

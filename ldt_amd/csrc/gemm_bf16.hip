@@ -79,16 +79,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.K / BK;
-    stage_tile<TBM>(a.X, a.ldx, m0, a.M, 0, smem, wave, lane);
-    stage_tile<TBN>(a.W, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
+    // split-K (EPI_F32, launcher): blockIdx.y = split s takes k in [s Ks, (s+1) Ks) and writes its own fp32 partial tile
+    const int ksplit = (EPI == EPI_F32 && a.splits > 1) ? a.K / a.splits : a.K;
+    const int kbase = (EPI == EPI_F32 && a.splits > 1) ? (int)blockIdx.y * ksplit : 0;
+    const bf16_t* Xk = a.X + kbase;
+    const bf16_t* Wk = a.W + kbase;
+    const int nk = ksplit / BK;
+    stage_tile<TBM>(Xk, a.ldx, m0, a.M, 0, smem, wave, lane);
+    stage_tile<TBN>(Wk, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
     // stages 1 .. NST-2 follow at once; wait until only they are outstanding (stage 0 landed)
     int ahead = 0;                                                    // stages issued beyond the one being waited for
 #pragma unroll
     for (int st = 1; st < NST - 1; ++st)
         if (st < nk) {
-            stage_tile<TBM>(a.X, a.ldx, m0, a.M, st * BK, smem + st * (XB + WB), wave, lane);
-            stage_tile<TBN>(a.W, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
+            stage_tile<TBM>(Xk, a.ldx, m0, a.M, st * BK, smem + st * (XB + WB), wave, lane);
+            stage_tile<TBN>(Wk, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
             ++ahead;
         }
     if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
@@ -105,8 +110,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
         if (kt + NST - 1 < nk) {                                      // buffer of stage kt-1 (NST = 3) / kt+1's own (NST = 2)
             int nb = cur + NST - 1; nb = nb >= NST ? nb - NST : nb;
             char* nx = smem + nb * (XB + WB);
-            stage_tile<TBM>(a.X, a.ldx, m0, a.M, (kt + NST - 1) * BK, nx, wave, lane);
-            stage_tile<TBN>(a.W, a.ldw, n0, a.N, (kt + NST - 1) * BK, nx + XB, wave, lane);
+            stage_tile<TBM>(Xk, a.ldx, m0, a.M, (kt + NST - 1) * BK, nx, wave, lane);
+            stage_tile<TBN>(Wk, a.ldw, n0, a.N, (kt + NST - 1) * BK, nx + XB, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += b[r];
             if (EPI == EPI_F32) {
-                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
+                float* o = reinterpret_cast<float*>(a.out) + (a.splits > 1 ? (long)blockIdx.y * a.split_stride : 0L) + (long)m * a.ldo + n;
                 if (full) *reinterpret_cast<f32x4*>(o) = v;
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
             } else if (EPI == EPI_RESID_F32) {
@@ -826,6 +831,21 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
                     LDT_EARG, "gemm: gate needs rows_per_sample>0 and 16-byte aligned strides");
     }
     LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm: bias must be 16-byte aligned");
+    if (a->splits > 1) {
+        // split-K (small-M regime: the residual GEMMs of a 1-2k-row batch have too few output tiles to fill 256 CUs with a tile large
+        // enough to keep the operand stream under the L2 -> LDS rate): fp32 partial tiles, reduced by the consumer (ldt_ln_launch)
+        LDT_REQUIRE(epi == EPI_F32 && !a->bias, LDT_EARG, "gemm: split-K writes raw fp32 partials (EPI_F32, no bias)");
+        LDT_REQUIRE(a->splits <= 16 && a->K % (a->splits * BK) == 0 && a->split_stride >= (long)a->M * a->ldo, LDT_ESHAPE,
+                    "gemm: split-K needs K=%d a multiple of splits*%d and split_stride >= M*ldo", a->K, BK);
+        auto nt = [&](int bm, int bn) { return (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
+        static const int sk_shape = getenv("LDT_GEMM_SPLITK_SHAPE") ? atoi(getenv("LDT_GEMM_SPLITK_SHAPE")) : -1;   // tools/dbg
+        const int shape = sk_shape >= 0 ? sk_shape : (nt(128, 128) * a->splits >= 2 * LDT_NUM_CUS) ? 0 : (nt(128, 64) * a->splits >= 2 * LDT_NUM_CUS ? 1 : 2);
+        dim3 block(256);
+        if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), block, 0, stream, *a);
+        else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 64>), dim3((unsigned)nt(128, 64), (unsigned)a->splits), block, 0, stream, *a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 64, 64, 3>), dim3((unsigned)nt(64, 64), (unsigned)a->splits), block, 0, stream, *a);
+        return ldt_check_launch("gemm_bf16_nt(split-K)");
+    }
     const int tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     const int force = gemm_variant();
     // 256^2 persistent kernel when its tiles fill at least 5/8 of the workgroups this launch may use (all CUs, or a

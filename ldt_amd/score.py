@@ -183,6 +183,8 @@ class Score(nn.Module):
             self._cond_cache = {key: (kv, S, pts_cond)}
         return self._cond_cache[key][:2]
 
+    SPLITK_MAX_ROWS, SPLITK_PARTS = 4096, 8      # ldt_score_plan.splitk_ws: offered to the C++ forward for batches of <= 4096 token rows
+
     def _workspace(self, B, T, slot=0):
         """Activation buffers of a (B, T) batch; `slot` separates the sub-batches that run concurrently on their own streams."""
         k = (B, T, self._device(), slot)
@@ -197,6 +199,8 @@ class Score(nn.Module):
                 "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
                 "stats": torch.empty((max(D // 256, 1), M, 2), dtype=torch.float32, device=dev),
             }
+            if M <= self.SPLITK_MAX_ROWS and D % 256 == 0 and D <= 1024:          # small batch: split-K partials of the residual GEMMs
+                self._ws[k]["P"] = torch.empty((self.SPLITK_PARTS, M, D), dtype=torch.float32, device=dev)
         return self._ws[k]
 
     def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0, monitor=None):
@@ -218,6 +222,8 @@ class Score(nn.Module):
         p.mod, p.mod_step_stride, p.mod_sample_stride = mod.data_ptr(), mod_step_stride, mod_sample_stride
         for nm in ("xin", "X", "Hb", "QKV", "Ob", "U"):
             setattr(p, nm, W[nm].data_ptr())
+        if "P" in W:
+            p.splitk_ws, p.splitk_parts = W["P"].data_ptr(), W["P"].shape[0]
         if kv_cond:
             p.cond_tokens = cond_tokens
             for l, kv in kv_cond.items():

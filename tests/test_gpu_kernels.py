@@ -538,3 +538,35 @@ torch.save(outs, sys.argv[1])
         assert torch.equal(res["1"][k], res["0"][k]), "XRING epilogue differs from the register epilogue in %s" % k
     ref = res["0"]["x1"]
     assert bool(torch.isfinite(ref).all()) and float(ref.abs().mean()) > 0.1
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(2048, 1024, 4096, 4), (1024, 1024, 1024, 4), (2048, 1024, 1024, 2), (384, 256, 512, 8)])
+def test_splitk_gemm_and_residual_layernorm(M, N, K, splits):
+    """Small-batch regime (T = 32 latents): the residual GEMMs run split over K into fp32 partials and the LayerNorm that follows does
+    x += gate * (sum of partials + bias) before normalising (include/ldt_hip.h) — vs the unsplit RESID_F32 GEMM + LayerNorm kernels
+    and vs fp64."""
+    from ldt_amd._lib import EPI_RESID_F32
+    g = torch.Generator().manual_seed(M + N + K + splits)
+    a = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5); b = torch.randn(N, generator=g)
+    x0 = torch.randn(M, N, generator=g)
+    rps = 128
+    gate = torch.randn(M // rps, N, generator=g); sh = 0.3 * torch.randn(M // rps, N, generator=g); sc = 0.3 * torch.randn(M // rps, N, generator=g)
+    parts = ops.gemm_bf16_splitk(dev(a, torch.bfloat16), dev(w, torch.bfloat16), splits)
+    ks = K // splits
+    for s_ in range(splits):
+        ref = a[:, s_ * ks:(s_ + 1) * ks].double() @ w[:, s_ * ks:(s_ + 1) * ks].double().T
+        assert rel_mse(parts[s_].cpu(), ref) < 1e-9
+    xd = dev(x0.clone())
+    h = ops.layernorm_modulate_resid_(xd, parts, bias=dev(b), gate=dev(gate), shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
+    xref = x0.double() + gate.double().repeat_interleave(rps, 0) * (a.double() @ w.double().T + b.double())
+    assert rel_mse(xd.cpu(), xref) < 1e-10
+    ln = (xref - xref.mean(1, keepdim=True)) / torch.sqrt(xref.var(1, unbiased=False, keepdim=True) + 1e-6)
+    href = ln * (1 + sc.double().repeat_interleave(rps, 0)) + sh.double().repeat_interleave(rps, 0)
+    assert rel_mse(h.float().cpu(), href) < 1e-5
+    # the unsplit kernels on the same inputs: same bf16 output up to fp32 summation order
+    x1 = dev(x0.clone())
+    ops.gemm_bf16(dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(b), EPI_RESID_F32, out=x1, resid=x1, gate=dev(gate), gate_sample_stride=N, rows_per_sample=rps)
+    h1 = ops.layernorm_modulate(x1, shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
+    assert rel_mse(xd.cpu(), x1.cpu()) < 1e-12 and rel_mse(h.float().cpu(), h1.float().cpu()) < 1e-6
+    again = ops.layernorm_modulate_resid_(dev(x0.clone()), parts, bias=dev(b), gate=dev(gate), shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
+    assert torch.equal(again, h)                                      # fixed summation order
