@@ -297,14 +297,17 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     bool fold = p->fold && p->stats && sstr == 0 && M % 256 == 0 && D % 256 == 0 && D <= 1024 && F % 256 == 0;
     for (int l = 0; l < p->blocks && fold; ++l) fold = !p->kv_cond[l];
     const long fstep = p->fold_step_stride, fblk = 6L * D + 2L * F;   // per block: S_qkv[3D] | C_qkv[3D] | S_up[F] | C_up[F]
-    // Split-K for the residual GEMMs of a small batch (include/ldt_hip.h, ldt_score_plan.splitk_ws): with N = hidden = 1024 a 1-2k-row
-    // batch has 32-128 output tiles of 128^2 for 256 CUs; smaller tiles stream 2-4x the operand bytes through the L2 -> LDS path,
-    // which then bounds the kernel (mlp.out at M = 2048: 39 us on 64^2 tiles against 14 us of MFMA work).  K is cut so that
-    // ~512 workgroups exist; the partial tiles are summed by the LayerNorm kernel that follows (ln_mod_vec_kernel<.., true>).
-    static const int sk_env = getenv("LDT_SPLITK") ? atoi(getenv("LDT_SPLITK")) : -1;   // 0 off; n > 1 forces n splits (tools/dbg, tests)
+    // Split-K for the residual GEMMs of a small batch (include/ldt_hip.h, ldt_score_plan.splitk_ws) — OPT-IN (LDT_SPLITK=1, or =n to
+    // force n splits).  With N = hidden = 1024 a 1-2k-row batch has 32-128 output tiles of 128^2 for 256 CUs, and smaller tiles stream
+    // 2-4x the operand bytes through the L2 -> LDS path; cutting K makes ~512 workgroups of 128^2 and moves the residual add into the
+    // LayerNorm kernel that follows (ln_resid_row_kernel).  Measured (round 3, tools/dbg/splitk_bench.py, profiles/r03_t32_*): the
+    // 2-phase 128^2 kernel is bound per workgroup (~0.65 PFLOP/s chip-wide at every tile count), so mlp.out at M = 2048 only goes
+    // 30 -> 26.5 us while the reducing LayerNorm costs +5-10 us: no net gain — kept for the parity tests and as the seam for a faster
+    // mid-size tile kernel.
+    static const int sk_env = getenv("LDT_SPLITK") ? atoi(getenv("LDT_SPLITK")) : 0;    // 0 off (default); 1 automatic; n > 1 forces n splits
     const long tiles128 = (long)((M + 127) / 128) * ((D + 127) / 128);
     int sk_o = 1, sk_d = 1;
-    if (!fold && p->splitk_ws && p->splitk_parts >= 2 && sk_env != 0 && D % 256 == 0 && D <= 1024 && (tiles128 < 2 * LDT_NUM_CUS || sk_env > 1)) {
+    if (!fold && p->splitk_ws && p->splitk_parts >= 2 && sk_env > 0 && D % 256 == 0 && D <= 1024 && (tiles128 < 2 * LDT_NUM_CUS || sk_env > 1)) {
         auto pick = [&](int K) {
             int want = sk_env > 1 ? sk_env : (int)((2 * LDT_NUM_CUS + tiles128 - 1) / tiles128);
             if (want > p->splitk_parts) want = p->splitk_parts;

@@ -570,3 +570,36 @@ def test_splitk_gemm_and_residual_layernorm(M, N, K, splits):
     assert rel_mse(xd.cpu(), x1.cpu()) < 1e-12 and rel_mse(h.float().cpu(), h1.float().cpu()) < 1e-6
     again = ops.layernorm_modulate_resid_(dev(x0.clone()), parts, bias=dev(b), gate=dev(gate), shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
     assert torch.equal(again, h)                                      # fixed summation order
+
+
+def test_score_forward_with_splitk_path_matches_default(tmp_path):
+    """The opt-in split-K orchestration of the Score forward (LDT_SPLITK, csrc/api.hip: fc_o / mlp.out as fp32 partials, the residual
+    add + reduction inside the following LayerNorm, incl. the FinalLayer's) equals the default path up to fp32 summation order, for the
+    batch-shared (fused-loop) and the per-sample AdaLN addressing.  Hidden 1024, 3 blocks, M = 1024 rows; child processes (the
+    switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    child = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import ldt_amd
+cfg = ldt_amd.airplane_config(latent_tokens=32, sample_N=10, **{"score.num_blocks": 3})
+torch.manual_seed(3)
+score = ldt_amd.Score(cfg.score).cuda()
+g = torch.Generator().manual_seed(1)
+x = torch.randn(32, 32, cfg.score.z_dim, generator=g).cuda()
+t = (torch.rand(32, generator=g) * 0.9 + 0.05).cuda()
+torch.save(dict(shared=score.forward_shared_t(x, 0.4).cpu(), per_sample=score(x, t).cpu()), sys.argv[1])
+''' % ROOT
+    res = {}
+    for sk in ("0", "1", "4"):
+        out = tmp_path / ("sk%s.pt" % sk)
+        r = subprocess.run([sys.executable, "-c", child, str(out)], env=dict(os.environ, LDT_SPLITK=sk), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[sk] = torch.load(out)
+    for sk in ("1", "4"):
+        for k in ("shared", "per_sample"):
+            e = rel_mse(res[sk][k], res["0"][k])
+            assert 0 < e < 1e-9, (sk, k, e)                       # taken (not bit-identical) and equal up to summation order
