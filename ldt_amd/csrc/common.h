@@ -47,6 +47,17 @@ int ldt_check_launch(const char* what);   // hipGetLastError -> status (+ messag
 
 __host__ __device__ static inline bool ldt_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Order-independent accumulation of fp64 partial sums across workgroups (LocalGrouper statistics): the partials are added as
+// 64-bit fixed-point integers (2^-20 resolution per wave partial, |sum| < 2^43 ~ 8.8e12: integer adds commute, so the result does not depend on the
+// arrival order of the atomics — two runs of the same input are bit-identical), and read back as doubles.
+#define LDT_FX_SCALE 1048576.0               /* 2^20 */
+__device__ __forceinline__ void fx_atomic_add(double* slot, double v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * LDT_FX_SCALE));
+}
+__device__ __forceinline__ double fx_load(const double* slot) {
+    return (double)(long long)(*reinterpret_cast<const unsigned long long*>(slot)) * (1.0 / LDT_FX_SCALE);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(512) void grouper_mlp_kernel(const GroupMlpArgs a) 
             const int cl = (int)(f / items), item = (int)(f - (long)cl * items);
             const int b = a.flat ? cl : xcd + 8 * cl;
             if (b != b_prev) {                                             // per-sample unbiased std of (g - anchor), layers.py:311-312
-                const double mean = a.stats[2 * b] / cnt;
-                const double var = (a.stats[2 * b + 1] - cnt * mean * mean) / (cnt - 1.0);
+                const double mean = fx_load(&a.stats[2 * b]) / cnt;
+                const double var = (fx_load(&a.stats[2 * b + 1]) - cnt * mean * mean) / (cnt - 1.0);
                 inv = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-5f);
                 b_prev = b;
             }

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const float* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (lane == 0) { atomicAdd(&stats[2 * b], s1); atomicAdd(&stats[2 * b + 1], s2); }
+    if (lane == 0) { fx_atomic_add(&stats[2 * b], s1); fx_atomic_add(&stats[2 * b + 1], s2); }    // order-independent (common.h)
 }
 
 // 'anchor' statistics, vector form (D % 4 == 0, D / 4 <= 32: the shipped 128- and 64-channel groupers): one wave per group of
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void group_stats_vec_kernel(const float* __res
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
-    if (lane == 0) { atomicAdd(&stats[2 * b], t1); atomicAdd(&stats[2 * b + 1], t2); }
+    if (lane == 0) { fx_atomic_add(&stats[2 * b], t1); fx_atomic_add(&stats[2 * b + 1], t2); }    // order-independent (common.h)
 }
 
 template <bool CENTER>
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void group_build_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const long rows = (long)S * k;
     const double cnt = (double)rows * (D + 3);
-    const double mean = stats[2 * b] / cnt;
-    const double var = (stats[2 * b + 1] - cnt * mean * mean) / (cnt - 1.0);
+    const double mean = fx_load(&stats[2 * b]) / cnt;
+    const double var = (fx_load(&stats[2 * b + 1]) - cnt * mean * mean) / (cnt - 1.0);
     const float inv = 1.0f / ((float)sqrt(var > 0.0 ? var : 0.0) + 1e-5f);
     for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4L) {
         const int sidx = (int)(r / k);
