@@ -117,6 +117,19 @@ def measured_traffic(symbol):
     return e["hbm_bytes_per_launch"], prov
 
 
+def measured_mfma_util(symbol):
+    """MFMA utilisation of `symbol` from the committed PMC pass (profiles/mfma_util.json, tools/reduce_pmc_mfma.py):
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  None when absent or collected on other kernel sources."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "mfma_util.json")) as f:
+            e = json.load(f).get(symbol)
+    except (OSError, ValueError):
+        e = None
+    if not e or e.get("csrc_sha") != csrc_sha():
+        return None, ("no measurement committed" if not e else "stale: kernel sources changed since the PMC pass (value withheld: %.3f)" % e["mfma_util"])
+    return e["mfma_util"], e.get("source")
+
+
 def roofline_pass(trainer, cfg, B, reps=3):
     """HIP-event timing of every launch of one Score forward (same stream), averaged over `reps` passes."""
     from ldt_amd import _lib, ops
@@ -174,6 +187,8 @@ def roofline_pass(trainer, cfg, B, reps=3):
             r = {"bound": "mfma", "achieved": k["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(k["tflops"] / PEAK_BF16_TFLOPS, 4), "flops_per_launch": flops[name]}
         tr_, prov = measured_traffic(sym)
+        mu, mu_src = measured_mfma_util(sym)
+        r.update(mfma_util=mu, mfma_util_source=mu_src)
         r.update(traffic=tr_, traffic_source=prov, kernel=sym, op=name, avg_launch_ms=k["avg_ms"], ms_per_forward=k["ms_per_forward"],
                  ln_folding=folded)
         roofs[name] = r
