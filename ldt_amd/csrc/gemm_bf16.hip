@@ -746,6 +746,265 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #undef ISSUE_W
 }
 
+// =================================================================================================
+// v3 ("full-line"): the same 8-wave ping-pong 256x256 kernel with the operand stream rebuilt around WHOLE 128-B LINES.
+//
+// Round 3 measurement (tools/dbg/gemm4w_asm.hip, profiles/r03_gemm4w_*): v2's DMA pieces are 16 rows x 64 B (32-deep sub-tiles),
+// so every 128-B line of X / W is requested twice, one sub-tile apart, and the CU's 32 KiB L1 has seen 64 KiB of other lines in
+// between: the L2 -> L1 fill traffic is 2x the operand bytes.  Alone, that operand stream takes as long as the MFMAs of the GEMM
+// (80 us for 137 GFLOP); with pieces of 8 rows x 128 B it takes 48-52 us.
+//
+//   * K is consumed in 64-deep K-TILES: LDS = 2 buffers x (X[256][64] | W[256][64]) bf16 = 2 x 64 KiB, rows of 128 B, the 16-B chunk
+//     index XORed with (row >> 1) & 7 (conflict-free ds_read_b128 of 16x32 fragments; on the DMA source address and the read address).
+//   * A K-tile = two 32-deep halves = four phases p0..p3 of v2's shape (16 MFMAs per wave and phase, two staggered groups).  During
+//     K-tile s the NEXT K-tile is requested into the other buffer, part by part as that buffer's rows retire (>= 3 phases after
+//     their last read):   p0: W(s+1), 4 pieces per wave     p1: X rows {0..63, 128..191}(s+1), 2 pieces     p2: the other X rows, 2.
+//   * Two counted waits per K-tile: p0 `vmcnt(4)` (X rows 64.. of THIS K-tile, read in p1; only W(s+1) may be in flight) and
+//     p3 `vmcnt(2)` (W and the first X half of s+1, read in the next p0).  Both sit before the phase's first barrier, the reads they
+//     cover come two barriers later (v2's RAW rule).  The first p0 after an epilogue allows for the epilogue's stores.
+//   * Operand addresses: a wave-uniform base (SGPRs: tile origin + k) + per-lane 32-bit offsets that never change (8 VGPRs), so the
+//     stream advance is scalar.  Interior tiles only (M, N multiples of 256: the launcher falls back to v2 otherwise).
+// Tile order, epilogues (staged / LN-fold producer + consumer / XRING) and persistence are v2's.
+#ifndef LDT_GEMM_FL_DEFAULT
+#define LDT_GEMM_FL_DEFAULT 1          /* v3 measured 4-10 % faster per GEMM, -3.2 % per SDE step (round 3, tools/dbg/env_ab.py LDT_GEMM_FL) */
+#endif
+#define V3_BUF_BYTES 65536
+#define V3_OPER_BYTES 32768
+
+template <int EPI, int FOLD = FOLD_NONE, int XRING = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int lrow = lane & 15, lchk = lane >> 4;
+    const int nkt = a.K >> 6;
+
+    // ---- this workgroup's tile list (v2's: 8 contiguous chunks, one per XCD label; grouped order inside)
+    const int tiles_n = a.N / 256;
+    const int tiles = (a.M / 256) * tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int nx = G < 8 ? G : 8;
+    const int xcd = bid % nx, j = bid / nx;
+    const int wpx = (G - xcd + nx - 1) / nx;
+    const int c_lo = (int)((long)tiles * xcd / nx), c_hi = (int)((long)tiles * (xcd + 1) / nx);
+    const int my_tiles = (c_hi - c_lo - j + wpx - 1) / wpx > 0 ? (c_hi - c_lo - j + wpx - 1) / wpx : 0;
+    if (my_tiles == 0) return;
+    const int tiles_m = a.M / 256, gm = a.group_m;
+    auto tile_of = [&](int it, int& m0, int& n0) {
+        const int id = c_lo + j + it * wpx;
+        if (gm <= 1) { m0 = (id / tiles_n) * 256; n0 = (id % tiles_n) * 256; return; }
+        const int per = gm * tiles_n, g = id / per, r = id - g * per;
+        const int rows = min(gm, tiles_m - g * gm);
+        m0 = (g * gm + r % rows) * 256; n0 = (r / rows) * 256;
+    };
+
+    // ---- operand stream: per-lane byte offsets (constant) + wave-uniform LDS destinations + uniform bases
+    // piece = 8 rows x 128 B: lane -> row (lane >> 3) of the piece, LDS position lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7)
+    int wvo[4], xavo[2], xbvo[2];                                        // global byte offsets from the (tile row 0, k) element
+    int wds[4], xads[2], xbds[2];                                        // LDS byte offsets inside a buffer (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + (lane >> 3);
+        wvo[q] = r * (int)a.ldw * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        wds[q] = V3_OPER_BYTES + (wave * 4 + q) * 1024;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pj = wave * 2 + q;                                     // 0..15: rows 0..63 then 128..191 (m-tiles 0-3 of the two groups)
+        const int r0 = pj < 8 ? pj * 8 : 128 + (pj - 8) * 8;
+        const int ra = r0 + (lane >> 3), rb = ra + 64;
+        xavo[q] = ra * (int)a.ldx * 2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 4);
+        xbvo[q] = rb * (int)a.ldx * 2 + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
+        xads[q] = r0 * 128;
+        xbds[q] = (r0 + 64) * 128;
+    }
+    const char* sxb = nullptr;                                           // stream bases: X / W at the stream's (tile, K-tile)
+    const char* swb = nullptr;
+    int s_it = 0, s_kt = 0, s_inc = 128;                                 // tile iteration, K-tile inside it, bytes per advance (0 once parked)
+    auto seek = [&](int it) {
+        int m0, n0;
+        tile_of(it, m0, n0);
+        sxb = reinterpret_cast<const char*>(a.X + (long)m0 * a.ldx);
+        swb = reinterpret_cast<const char*>(a.W + (long)n0 * a.ldw);
+    };
+    auto advance = [&]() {                                               // after the last part (X rows 64..) of a K-tile was requested
+        sxb += s_inc; swb += s_inc;
+        if (++s_kt == nkt) {
+            s_kt = 0;
+            if (++s_it < my_tiles) seek(s_it);
+            else { sxb -= s_inc; swb -= s_inc; s_inc = 0; s_kt = -0x40000000; }   // parked: re-reads the last K-tile, never consumed
+        }
+    };
+    int gk = 0;                                                          // global K-tile counter of the CONSUMER (buffer = gk & 1)
+    auto issue_w = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(swb + wvo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + wds[q]), 16, 0, 0);
+    };
+    auto issue_xa = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sxb + xavo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + xads[q]), 16, 0, 0);
+    };
+    auto issue_xb = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sxb + xbvo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + xbds[q]), 16, 0, 0);
+    };
+    seek(0);
+
+    // step-indexed (cache-cold) epilogue vectors of the FIRST tile, fetched ahead of everything else (as v2)
+    const float* gate = a.gate;
+    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
+    const float* ln_scale = (FOLD == FOLD_PRODUCER) ? a.ln_scale + (long)step * a.ln_step_stride : nullptr;
+    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
+    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
+    f32x4 g4_pre = {1.f, 1.f, 1.f, 1.f}, sc4_pre = {0.f, 0.f, 0.f, 0.f};
+    const bool pre_ok = (EPI == EPI_RESID_F32) && gate && a.gate_sample_stride == 0;
+    if (EPI == EPI_RESID_F32) {
+        int m0, n0;
+        tile_of(0, m0, n0);
+        if (pre_ok) g4_pre = *reinterpret_cast<const f32x4*>(gate + n0 + wn * 64 + (lane & 15) * 4);
+        if (FOLD == FOLD_PRODUCER) sc4_pre = *reinterpret_cast<const f32x4*>(ln_scale + n0 + wn * 64 + (lane & 15) * 4);
+    }
+
+    // prologue: K-tile 0 -> buffer 0
+    issue_w(smem2); issue_xa(smem2); issue_xb(smem2); advance();
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // W + first X half landed (this wave's pieces)
+    V2_BARRIER();
+    if (EPI == EPI_RESID_F32) asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
+
+    // per-lane LDS read bases inside a buffer: row * 128 + ((k-half * 4 + lchk) ^ ((row >> 1) & 7)) * 16; fragment i at + i * 2048
+    const int sw = (lrow >> 1) & 7;
+    const int xrb = (grp * 128 + lrow) * 128, wrb = V3_OPER_BYTES + (wn * 64 + lrow) * 128;
+    const int xb0 = xrb + ((lchk ^ sw) << 4), xb1 = xrb + (((4 + lchk) ^ sw) << 4);
+    const int wb0 = wrb + ((lchk ^ sw) << 4), wb1 = wrb + (((4 + lchk) ^ sw) << 4);
+
+    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
+                             : (FOLD == FOLD_PRODUCER) ? 57 : 32;
+    char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
+    bool prev_staged = false;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        int m0, n0;
+        tile_of(it, m0, n0);
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
+
+        enum { KT_PLAIN = 0, KT_FIRST = 1 /* first wait allows for the previous epilogue's stores */, KT_FOLD_DMA = 4, KT_FOLD_FINAL = 8 };
+        auto ktile = [&](auto flags_c) {
+            constexpr int FL = decltype(flags_c)::value;
+            const char* st = smem2 + (gk & 1) * V3_BUF_BYTES;            // buffer being consumed
+            char* nb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;            // buffer being refilled (K-tile gk + 1)
+            bf16x8 wf[4], xf[4];
+            // ---------------- p0: half 0 — W (4 n-tiles) + X m-tiles 0..3; DMA: W of the next K-tile; wait: this K-tile's X rows 64.. ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048);
+            issue_w(nb);
+            if (FL & KT_FOLD_DMA) {
+                if (wave < 2 * a.stats_parts) {
+                    const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
+                }
+                if (wave < 4 && lane < 32) {
+                    const float* src = (wave < 2 ? fold_S : fold_C) + n0 + (wave & 1) * 128 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_SC_OFF), 16, 0, 0);
+                }
+            }
+            if ((FL & KT_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
+            if ((FL & KT_FIRST) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + EPI_VMEM > 63 ? 63 : 4 + EPI_VMEM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p1: half 0 — X m-tiles 4..7; DMA: first X half of the next K-tile ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + (4 + i) * 2048);
+            issue_xa(nb);
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p2: half 1 — W + X m-tiles 0..3; DMA: second X half of the next K-tile ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048);
+            issue_xb(nb);
+            advance();
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p3: half 1 — X m-tiles 4..7; wait: W + first X half of the next K-tile ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + (4 + i) * 2048);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            ++gk;
+        };
+#define KTL(f) std::integral_constant<int, (f)>{}
+        if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 4 K-tiles
+            ktile(KTL(KT_FIRST)); ktile(KTL(KT_FOLD_DMA)); ktile(KTL(KT_PLAIN)); ktile(KTL(KT_FOLD_FINAL));
+            for (int kt = 4; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
+        } else {
+            ktile(KTL(KT_FIRST));
+            for (int kt = 1; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
+        }
+#undef KTL
+        if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
+
+        prev_staged = true;                                              // interior, aligned tiles only (launcher)
+        if (XRING) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V2_BARRIER();
+            v2_epilogue_staged<EPI, FOLD, 1>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
+                                                true, g4_pre, sc4_pre, smem2 + wave * 16384);
+        } else
+            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
+                                          it == 0 && (pre_ok || FOLD == FOLD_PRODUCER), g4_pre, sc4_pre);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail requests before exit
+}
+
 // rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
 static std::atomic<int> g_group_m{-1};
 extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LDT_OK; }
@@ -776,11 +1035,28 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;
     const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
+    // v3 (full-line operand stream, 64-deep K-tiles): interior + aligned tiles only.  LDT_GEMM_FL=0 keeps v2 everywhere (A/B runs).
+    static const int fl_env = getenv("LDT_GEMM_FL") ? atoi(getenv("LDT_GEMM_FL")) : LDT_GEMM_FL_DEFAULT;
+    const bool fl = fl_env && EPI != EPI_DISCARD && a->dbg == 0 && a->K % 64 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 &&
+                    (EPI != EPI_RESID_F32 || (a->ldr % 4 == 0 && (!a->gate || a->gate_sample_stride % 4 == 0))) &&
+                    (EPI != EPI_RELU_BF16 || !a->skip || a->lds_ % 4 == 0);
     if constexpr (EPI == EPI_RESID_F32) {
         if (xring && grid == tiles && a->dbg == 0) {                     // every workgroup has exactly one tile: the ring is idle in its epilogue
+            if (fl) {
+                LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256f");
+                hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+                return ldt_check_launch("gemm_bf16_nt_256f");
+            }
             LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256");
             hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
             return ldt_check_launch("gemm_bf16_nt_256");
+        }
+    }
+    if constexpr (EPI != EPI_DISCARD) {
+        if (fl) {
+            LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256f");
+            hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+            return ldt_check_launch("gemm_bf16_nt_256f");
         }
     }
     hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);

@@ -496,11 +496,15 @@ def test_resid_ring_epilogue_is_bit_identical_to_plain_loads():
         assert rel_mse(outs[0][0].cpu(), ref) < 1e-9
 
 
-def test_resid_ring_epilogue_bit_equal_to_register_epilogue(tmp_path):
-    """the XRING epilogue of the one-tile-per-workgroup residual GEMMs (residual rows fetched by LDS-DMA into the idle
-    operand ring, hand-counted `s_waitcnt vmcnt(N)`) must equal the plain register epilogue BIT FOR BIT — a toolchain that
-    emitted one VMEM op more or fewer per pass would read rows before they land.  Same seeded problem (plain RESID_F32 and the
-    LN-fold producer, M = 16,384 x N = 1,024: exactly 256 tiles) in two child processes, LDT_RESID_RING=1 (default) and =0."""
+def test_gemm256_variants_bit_equal(tmp_path):
+    """The 256x256 GEMM has four code paths for the same arithmetic: operand stream v2 (16-row x 64-B DMA pieces, 32-deep ring) or
+    v3 (whole 128-B lines, 64-deep K-tiles: LDT_GEMM_FL), and for one-tile-per-workgroup residual GEMMs the XRING epilogue (residual
+    rows by LDS-DMA through the idle operand ring, hand-counted `s_waitcnt vmcnt(N)`: LDT_RESID_RING) or the register epilogue.
+    Every MFMA accumulates the same k-slices in the same order in all of them, so all four must agree BIT FOR BIT (a
+    toolchain that emitted one VMEM op more or fewer per pass, or a mis-counted wait, would read data before it lands).
+    Same seeded problems in four child processes: plain RESID_F32 and the LN-fold producer (M = 16,384 x N = 1,024: exactly 256
+    tiles), the LN-fold consumer with GELU on a multi-tile persistent shape (N = 4,096: four tiles per workgroup) and a plain
+    bf16 projection (N = 3,072), each launched three times (run-to-run differences would betray a race)."""
     import os
     import subprocess
     import sys
@@ -509,35 +513,43 @@ def test_resid_ring_epilogue_bit_equal_to_register_epilogue(tmp_path):
 import sys, torch
 sys.path.insert(0, %r)
 from ldt_amd import ops
-from ldt_amd._lib import EPI_RESID_F32
+from ldt_amd._lib import EPI_RESID_F32, EPI_GELU_BF16, EPI_BF16
 g = torch.Generator().manual_seed(11)
 M, D, K = 16384, 1024, 1024
 a = torch.randn(M, K, generator=g).bfloat16().cuda(); w = (torch.randn(D, K, generator=g) / 32).bfloat16().cuda()
+a4 = torch.randn(M, 4 * K, generator=g).bfloat16().cuda(); w4 = (torch.randn(D, 4 * K, generator=g) / 64).bfloat16().cuda()
 b = torch.randn(D, generator=g).cuda(); gate = torch.randn(1, D, generator=g).cuda(); sc = (0.3 * torch.randn(D, generator=g)).cuda()
+wu = (torch.randn(4 * D, D, generator=g) / 32).bfloat16().cuda(); S = torch.randn(4 * D, generator=g).cuda(); C = torch.randn(4 * D, generator=g).cuda()
+wq = (torch.randn(3 * D, D, generator=g) / 32).bfloat16().cuda(); bq = torch.randn(3 * D, generator=g).cuda()
 x0 = torch.randn(M, D, generator=g).cuda()
 outs = {}
-for rep in range(3):                      # repeated launches: a latent race would show as run-to-run differences too
+for rep in range(3):
     x1 = x0.clone()
     ops.gemm_bf16(a, w, b, EPI_RESID_F32, out=x1, resid=x1, gate=gate, gate_sample_stride=0, rows_per_sample=M)
     x2 = x0.clone()
     xs, st = ops.gemm_resid_lnstats(a, w, b, x2, sc, gate=gate, gate_sample_stride=0, rows_per_sample=M)
-    cur = dict(x1=x1.cpu(), x2=x2.cpu(), xs=xs.cpu(), st=st.cpu())
+    x3 = x0.clone()
+    xs3, st3 = ops.gemm_resid_lnstats(a4, w4, b, x3, sc, gate=gate, gate_sample_stride=0, rows_per_sample=M)      # K = 4096 (mlp.out)
+    u = ops.gemm_lnfold(xs, wu, st, S, C, EPI_GELU_BF16)
+    q = ops.gemm_bf16(xs, wq, bq, EPI_BF16)
+    cur = dict(x1=x1.cpu(), x2=x2.cpu(), xs=xs.cpu(), st=st.cpu(), x3=x3.cpu(), xs3=xs3.cpu(), st3=st3.cpu(), u=u.cpu(), q=q.cpu())
     if outs:
         assert all(torch.equal(outs[k], cur[k]) for k in cur), "run-to-run difference"
     outs = cur
 torch.save(outs, sys.argv[1])
 ''' % ROOT
     res = {}
-    for ring in ("1", "0"):
-        out = tmp_path / ("ring%s.pt" % ring)
-        env = dict(os.environ, LDT_RESID_RING=ring)
+    for fl, ring in (("0", "0"), ("0", "1"), ("1", "1"), ("1", "0")):
+        out = tmp_path / ("fl%s_ring%s.pt" % (fl, ring))
+        env = dict(os.environ, LDT_GEMM_FL=fl, LDT_RESID_RING=ring)
         r = subprocess.run([sys.executable, "-c", child, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[ring] = torch.load(out)
-    for k in res["1"]:
-        assert torch.equal(res["1"][k], res["0"][k]), "XRING epilogue differs from the register epilogue in %s" % k
-    ref = res["0"]["x1"]
-    assert bool(torch.isfinite(ref).all()) and float(ref.abs().mean()) > 0.1
+        res[(fl, ring)] = torch.load(out)
+    base = res[("0", "0")]
+    for key, cur in res.items():
+        for k in base:
+            assert torch.equal(cur[k], base[k]), "LDT_GEMM_FL=%s LDT_RESID_RING=%s differs from the v2 register-epilogue path in %s" % (key + (k,))
+    assert bool(torch.isfinite(base["x1"]).all()) and float(base["x1"].abs().mean()) > 0.1 and float(base["u"].float().abs().mean()) > 0.01
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(2048, 1024, 4096, 4), (1024, 1024, 1024, 4), (2048, 1024, 1024, 2), (384, 256, 512, 8)])
