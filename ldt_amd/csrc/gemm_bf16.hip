@@ -768,6 +768,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #ifndef LDT_GEMM_FL_DEFAULT
 #define LDT_GEMM_FL_DEFAULT 1          /* v3 measured 4-10 % faster per GEMM, -3.2 % per SDE step (round 3, tools/dbg/env_ab.py LDT_GEMM_FL) */
 #endif
+#ifndef V3_SCHED
+#define V3_SCHED 0                      /* 0: requests per phase 4 (W) / 2 / 2 / 0;  1: 2 / 2 / 2 / 2 (tools/dbg) */
+#endif
 #define V3_BUF_BYTES 65536
 #define V3_OPER_BYTES 32768
 
@@ -838,11 +841,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
         }
     };
     int gk = 0;                                                          // global K-tile counter of the CONSUMER (buffer = gk & 1)
-    auto issue_w = [&](char* buf) {
+    auto issue_w = [&](char* buf, int q0 = 0, int q1 = 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(swb + wvo[q]),
-                                             (__attribute__((address_space(3))) void*)(buf + wds[q]), 16, 0, 0);
+            if (q >= q0 && q < q1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(swb + wvo[q]),
+                                                 (__attribute__((address_space(3))) void*)(buf + wds[q]), 16, 0, 0);
     };
     auto issue_xa = [&](char* buf) {
 #pragma unroll
@@ -912,7 +916,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048);
+#if V3_SCHED == 1
+            issue_w(nb, 0, 2);                                           // balanced form: 2 pieces per wave in every phase (tools/dbg A/B)
+#else
             issue_w(nb);
+#endif
             if (FL & KT_FOLD_DMA) {
                 if (wave < 2 * a.stats_parts) {
                     const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
@@ -926,8 +934,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
                 }
             }
             if ((FL & KT_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
-            if ((FL & KT_FIRST) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + EPI_VMEM > 63 ? 63 : 4 + EPI_VMEM) : "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            constexpr int P0W = V3_SCHED == 1 ? 2 : 4;                  // requests issued in p0 ahead of this wait
+            if ((FL & KT_FIRST) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W + EPI_VMEM > 63 ? 63 : P0W + EPI_VMEM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W) : "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -940,7 +949,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             // ---------------- p1: half 0 — X m-tiles 4..7; DMA: first X half of the next K-tile ----------------
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + (4 + i) * 2048);
+#if V3_SCHED == 1
+            issue_w(nb, 2, 4);
+#else
             issue_xa(nb);
+#endif
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -955,8 +968,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048);
+#if V3_SCHED == 1
+            issue_xa(nb);
+#else
             issue_xb(nb);
             advance();
+#endif
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -969,6 +986,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             // ---------------- p3: half 1 — X m-tiles 4..7; wait: W + first X half of the next K-tile ----------------
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + (4 + i) * 2048);
+#if V3_SCHED == 1
+            issue_xb(nb);
+            advance();
+#endif
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
