@@ -768,6 +768,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 #ifndef LDT_GEMM_FL_DEFAULT
 #define LDT_GEMM_FL_DEFAULT 1          /* v3 measured 4-10 % faster per GEMM, -3.2 % per SDE step (round 3, tools/dbg/env_ab.py LDT_GEMM_FL) */
 #endif
+#ifndef V3_PREISSUE
+#define V3_PREISSUE 1                   /* request a tile's second K-tile before the previous tile's epilogue stores */
+#endif
 #ifndef V3_SCHED
 #define V3_SCHED 0                      /* 0: requests per phase 4 (W) / 2 / 2 / 0;  1: 2 / 2 / 2 / 2 (tools/dbg) */
 #endif
@@ -878,9 +881,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
         if (FOLD == FOLD_PRODUCER) sc4_pre = *reinterpret_cast<const f32x4*>(ln_scale + n0 + wn * 64 + (lane & 15) * 4);
     }
 
-    // prologue: K-tile 0 -> buffer 0
+    // prologue: K-tile 0 -> buffer 0 (and, V3_PREISSUE, K-tile 1 -> buffer 1: the invariant at every tile start is then "K-tiles 0 and 1
+    // of this tile are requested", which lets a tile's SECOND K-tile be requested before the previous tile's epilogue stores — see below)
     issue_w(smem2); issue_xa(smem2); issue_xb(smem2); advance();
+#if V3_PREISSUE
+    issue_w(smem2 + V3_BUF_BYTES); issue_xa(smem2 + V3_BUF_BYTES); issue_xb(smem2 + V3_BUF_BYTES); advance();
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                    // W + first X half of K-tile 0 landed (this wave's pieces)
+#else
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // W + first X half landed (this wave's pieces)
+#endif
     V2_BARRIER();
     if (EPI == EPI_RESID_F32) asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
 
@@ -905,9 +914,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
 
-        enum { KT_PLAIN = 0, KT_FIRST = 1 /* first wait allows for the previous epilogue's stores */, KT_FOLD_DMA = 4, KT_FOLD_FINAL = 8 };
+        // V3_PREISSUE: in-order VMEM retirement makes every request issued AFTER an epilogue's stores wait for them (a 128 KiB tile drains
+        // in 2.5-5 us).  With K-tile 1 of the next tile requested BEFORE the stores, the first requests behind them (K-tile 2) are
+        // needed 8 phases after the epilogue instead of 4: KT_FIRST issues nothing, KT_FIRST / KT_SECOND count the stores into their waits.
+        enum { KT_PLAIN = 0, KT_FIRST = 1 /* first K-tile of a tile */, KT_SECOND = 2 /* second (V3_PREISSUE) */, KT_FOLD_DMA = 4, KT_FOLD_FINAL = 8 };
         auto ktile = [&](auto flags_c) {
             constexpr int FL = decltype(flags_c)::value;
+            constexpr bool SKIP = V3_PREISSUE && (FL & KT_FIRST);        // K-tile 1 of this tile was requested ahead (prologue / before the epilogue)
             const char* st = smem2 + (gk & 1) * V3_BUF_BYTES;            // buffer being consumed
             char* nb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;            // buffer being refilled (K-tile gk + 1)
             bf16x8 wf[4], xf[4];
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #if V3_SCHED == 1
             issue_w(nb, 0, 2);                                           // balanced form: 2 pieces per wave in every phase (tools/dbg A/B)
 #else
-            issue_w(nb);
+            if (!SKIP) issue_w(nb);
 #endif
             if (FL & KT_FOLD_DMA) {
                 if (wave < 2 * a.stats_parts) {
@@ -934,8 +947,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
                 }
             }
             if ((FL & KT_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
-            constexpr int P0W = V3_SCHED == 1 ? 2 : 4;                  // requests issued in p0 ahead of this wait
-            if ((FL & KT_FIRST) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W + EPI_VMEM > 63 ? 63 : P0W + EPI_VMEM) : "memory");
+            // requests issued after this K-tile's second X half (the data this wait is for): none / W of the next K-tile / (KT_FIRST with
+            // V3_PREISSUE) the whole pre-requested K-tile 1; after an epilogue also its stores (clamped to the 6-bit counter: only stricter)
+            constexpr int P0W = SKIP ? 8 : V3_SCHED == 1 ? 2 : 4;
+            constexpr bool AFTER_EPI = (FL & KT_FIRST) || (V3_PREISSUE && (FL & KT_SECOND));
+            if (AFTER_EPI && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W + EPI_VMEM > 63 ? 63 : P0W + EPI_VMEM) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W) : "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
@@ -952,7 +968,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #if V3_SCHED == 1
             issue_w(nb, 2, 4);
 #else
-            issue_xa(nb);
+            if (!SKIP) issue_xa(nb);
 #endif
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
@@ -971,8 +987,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #if V3_SCHED == 1
             issue_xa(nb);
 #else
-            issue_xb(nb);
-            advance();
+            if (!SKIP) { issue_xb(nb); advance(); }
 #endif
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
@@ -990,7 +1005,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             issue_xb(nb);
             advance();
 #endif
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (SKIP && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + EPI_VMEM > 63 ? 63 : 2 + EPI_VMEM) : "memory");   // W + X half of K-tile 1: older than the stores
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1004,16 +1020,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
         };
 #define KTL(f) std::integral_constant<int, (f)>{}
         if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 4 K-tiles
-            ktile(KTL(KT_FIRST)); ktile(KTL(KT_FOLD_DMA)); ktile(KTL(KT_PLAIN)); ktile(KTL(KT_FOLD_FINAL));
+            ktile(KTL(KT_FIRST)); ktile(KTL(KT_FOLD_DMA | KT_SECOND)); ktile(KTL(KT_PLAIN)); ktile(KTL(KT_FOLD_FINAL));
             for (int kt = 4; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
         } else {
-            ktile(KTL(KT_FIRST));
-            for (int kt = 1; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
+            ktile(KTL(KT_FIRST)); ktile(KTL(KT_SECOND));                 // (launcher: at least 2 K-tiles)
+            for (int kt = 2; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
         }
 #undef KTL
         if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
 
         prev_staged = true;                                              // interior, aligned tiles only (launcher)
+#if V3_PREISSUE
+        if (!XRING) {                                                    // K-tile 1 of the next tile -> the buffer the last K-tile has just left (all waves are past its reads)
+            char* pb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;
+            issue_w(pb); issue_xa(pb); issue_xb(pb); advance();
+        }
+#endif
         if (XRING) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             V2_BARRIER();
@@ -1058,7 +1080,7 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
     // v3 (full-line operand stream, 64-deep K-tiles): interior + aligned tiles only.  LDT_GEMM_FL=0 keeps v2 everywhere (A/B runs).
     static const int fl_env = getenv("LDT_GEMM_FL") ? atoi(getenv("LDT_GEMM_FL")) : LDT_GEMM_FL_DEFAULT;
-    const bool fl = fl_env && EPI != EPI_DISCARD && a->dbg == 0 && a->K % 64 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 &&
+    const bool fl = fl_env && EPI != EPI_DISCARD && a->dbg == 0 && a->K % 64 == 0 && a->K >= 128 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 &&
                     (EPI != EPI_RESID_F32 || (a->ldr % 4 == 0 && (!a->gate || a->gate_sample_stride % 4 == 0))) &&
                     (EPI != EPI_RELU_BF16 || !a->skip || a->lds_ % 4 == 0);
     if constexpr (EPI == EPI_RESID_F32) {
