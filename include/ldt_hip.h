@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 14
+#define LDT_ABI_VERSION 15
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -174,6 +174,11 @@ int ldt_lincomb4(const float* a0, const float* a1, const float* a2, const float*
  * ldt_widen_bf16: fp32 copy of a packed bf16 panel (exact). */
 int ldt_vpsde_score(const float* params, const float* t, float beta0, float beta1, float sigma2_0, float* out, int32_t B,
                     int64_t per_sample, void* stream);
+/* ldt_sde_score: the same for the other SDE families make_diffusion builds (diffusion/diffusion_continuous.py:18-29):
+ *   kind 0 vpsde (c0..c2 = beta0, beta1, sigma2_0), 1 sub_vpsde (:705-707; same constants), 2 vesde / geometric_sde
+ *   (:746-747 / :615-616; c0..c2 = sigma2_min, sigma2_max / sigma2_min, sigma2_0). */
+int ldt_sde_score(const float* params, const float* t, int32_t kind, float c0, float c1, float c2, float* out, int32_t B,
+                  int64_t per_sample, void* stream);
 int ldt_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
 

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -65,6 +65,7 @@ SIGNATURES = {
     "ldt_pndm_transfer": [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _i64, _vp],
     "ldt_lincomb4": [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _i64, _vp],
     "ldt_vpsde_score": [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
+    "ldt_sde_score": [_vp, _vp, _i32, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
     "ldt_add_f32": [_vp, _vp, _vp, _i64, _vp],
     "ldt_widen_bf16": [_vp, _vp, _i64, _vp],
     "ldt_fold_mean_ratio": [_vp, _i32, _i64, _i32, _vp, _vp],

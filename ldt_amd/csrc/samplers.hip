@@ -162,6 +162,55 @@ extern "C" int ldt_vpsde_score(const float* params, const float* t, float beta0,
     return ldt_check_launch("vpsde_score");
 }
 
+// The same score for the other SDE families of diffusion/diffusion_continuous.py (make_diffusion :18-29): kind 1 = sub-VP
+// (:705-707: var = (1 - e)^2 + sigma2_0 e, e = exp(-beta0 t - (beta1 - beta0) t^2 / 2); c = beta0, beta1, sigma2_0),
+// kind 2 = VE and geometric (:746-747, :615-616: var = smin ratio^t - smin + sigma2_0; c = smin, ratio = smax / smin, sigma2_0),
+// kind 0 = the VP form above.  fp32, the reference's op order.
+__global__ __launch_bounds__(256) void sde_score_kernel(const float* __restrict__ params, const float* __restrict__ t, int kind, float c0, float c1,
+                                                        float c2, float* __restrict__ out, long per4) {
+    const float tb = t[blockIdx.y];
+    float sd;
+    {
+#pragma clang fp contract(off)
+        float var;
+        if (kind == 2) {
+            var = c0 * powf(c1, tb) - c0 + c2;
+        } else {
+            const float a = -c0 * tb;
+            const float b = (0.5f * (c1 - c0)) * tb * tb;
+            const float e = expf(a - b);
+            if (kind == 1) {
+                const float om = 1.0f - e;
+                var = om * om + c2 * e;
+            } else {
+                var = 1.0f - (1.0f - c2) * e;
+            }
+        }
+        sd = sqrtf(var);
+    }
+    const float* src = params + (long)blockIdx.y * per4 * 4;
+    float* dst = out + (long)blockIdx.y * per4 * 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < per4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = -v[j] / sd;
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+    }
+}
+extern "C" int ldt_sde_score(const float* params, const float* t, int32_t kind, float c0, float c1, float c2, float* out, int32_t B,
+                             int64_t per_sample, void* stream) {
+    LDT_REQUIRE(params && t && out, LDT_EARG, "sde_score: null pointer");
+    LDT_REQUIRE(kind >= 0 && kind <= 2, LDT_EARG, "sde_score: kind=%d (0 vpsde, 1 sub_vpsde, 2 vesde / geometric_sde)", kind);
+    LDT_REQUIRE(B > 0 && B <= 65535 && per_sample > 0 && per_sample % 4 == 0 && ldt_aligned16(params) && ldt_aligned16(out), LDT_ESHAPE,
+                "sde_score: B=%d in [1, 65535], per_sample=%ld a multiple of 4, 16-byte aligned buffers", B, (long)per_sample);
+    long bx = (per_sample / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(sde_score_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params, t,
+                       (int)kind, c0, c1, c2, out, (long)(per_sample / 4));
+    return ldt_check_launch("sde_score");
+}
+
 // out = a + b (fp32; c = t_emb + label / image-condition embedding, model/scorenet/score.py:135).  out may alias a or b.
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];

@@ -28,46 +28,43 @@ PREDICTORS = ("reversediffusion", "ancestral", "eulermaruyama", "ddim")
 
 
 def make_diffusion(args):
+    """diffusion_continuous.py:18-29."""
+    if args.sde_type == "geometric_sde":
+        return DiffusionGeometric(args)
     if args.sde_type == "vpsde":
         return DiffusionVPSDE(args)
-    raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % (args.sde_type,))
+    if args.sde_type == "sub_vpsde":
+        return DiffusionSubVPSDE(args)
+    if args.sde_type == "vesde":
+        return DiffusionVESDE(args)
+    raise ValueError("Unrecognized sde type: {}".format(args.sde_type))
 
 
-class DiffusionVPSDE:
+class DiffusionBase:
+    """diffusion_continuous.py:32-624: the samplers, written against the schedule a subclass supplies (f, g2, var, e2int_f).
+    `score_kind` / `score_consts()` name the subclass's var(t) for ldt_sde_score (Trainer.score_fn)."""
+    score_kind = None
+
     def __init__(self, args):
         self.sigma2_0 = args.sigma2_0
         self.sde_type = args.sde_type
         self.time_eps = args.time_eps
         self.sample_time_eps = args.sample_time_eps
-        self.beta_start = args.beta_start
-        self.beta_end = args.beta_end
-        self.train_N = args.train_N
-        if args.sample_mode == "discrete":
-            self.N = args.sample_N
-            self.betas = torch.from_numpy(np.linspace(self.beta_start / self.N, self.beta_end / self.N, self.N,
-                                                      dtype=np.float64)).to(torch.float32)
-            self.alpha = 1.0 - self.betas
-            self.alphas_cump = self.alpha.cumprod(dim=0)
-
-    # ---- schedule (tensor in, tensor out; any device) ------------------------------------------
-    def g2(self, t):
-        return self.beta_start + (self.beta_end - self.beta_start) * t
 
     def f(self, t):
-        return -0.5 * self.g2(t)
+        raise NotImplementedError
+
+    def g2(self, t):
+        raise NotImplementedError
 
     def var(self, t):
-        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
-            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+        raise NotImplementedError
+
+    def e2int_f(self, t):
+        raise NotImplementedError
 
     def std(self, t):
         return torch.sqrt(self.var(t))
-
-    def e2int_f(self, t):
-        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
-
-    def discrete(self, idx):
-        return self.betas.index_select(0, idx), self.alpha.index_select(0, idx)
 
     # ---- per-step coefficient table for ldt_sampler_step ------------------------------------------
     def step_table(self, N, predictor, time_eps, probability_flow=False):
@@ -81,18 +78,17 @@ class DiffusionVPSDE:
             beta = self.betas[idx]
             coef = torch.stack([beta, self.std(ts), torch.sqrt(1. - beta), torch.sqrt(beta)], 1)
             return ts, coef.contiguous(), 0
-        t64 = ts.double()
         std = self.std(ts).double()
         if predictor == "reversediffusion":                                 # :141-150
             dt = (1 - time_eps) / N
-            g2 = self.g2(t64); ff = self.f(t64)
+            g2 = self.g2(ts).double(); ff = self.f(ts).double()     # fp32 like upstream, then folded in fp64
             k = 0.5 if probability_flow else 1.0
             A = 1 - ff * dt
             Bc = -g2 * k * dt / std                # x_mean = x - (f x - g2 k score) dt, score = -params/std
             Cc = torch.zeros_like(g2) if probability_flow else torch.sqrt(g2) * np.sqrt(dt)
         elif predictor == "eulermaruyama":                                  # :182-191
             dt = -1.0 / N
-            g2 = self.g2(t64); ff = self.f(t64)
+            g2 = self.g2(ts).double(); ff = self.f(ts).double()     # fp32 like upstream, then folded in fp64
             k = 0.5 if probability_flow else 1.0
             A = 1 + ff * dt
             Bc = g2 * k * dt / std
@@ -122,8 +118,6 @@ class DiffusionVPSDE:
         behaviour is restated from its published semantics — parity unpinned."""
         import time
         from scipy.integrate import solve_ivp
-        if self.sde_type != "vpsde":
-            raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % (self.sde_type,))
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("sample_model_ode: device %s — the HIP path has no CPU fallback" % (device,))
@@ -393,6 +387,141 @@ class DiffusionVPSDE:
                 noise = lincomb((e1, e2, e3, e4), (1.0, 2.0, 2.0, 1.0), 1 / 6)
             x = transfer(x, timesteps[idx * 2 - 1], timesteps[t_next * 2 - 1], noise)               # :304-307
         return x
+
+
+class DiffusionVPSDE(DiffusionBase):
+    """diffusion_continuous.py:626-678: dz = -beta(t)/2 z dt + sqrt(beta(t)) dW, linear beta(t)."""
+    score_kind = 0
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.beta_start = args.beta_start
+        self.beta_end = args.beta_end
+        self.train_N = args.train_N
+        if args.sample_mode == "discrete":
+            self.N = args.sample_N
+            self.betas = torch.from_numpy(np.linspace(self.beta_start / self.N, self.beta_end / self.N, self.N,
+                                                      dtype=np.float64)).to(torch.float32)
+            self.alpha = 1.0 - self.betas
+            self.alphas_cump = self.alpha.cumprod(dim=0)
+
+    def score_consts(self):
+        return self.beta_start, self.beta_end, self.sigma2_0
+
+    # ---- schedule (tensor in, tensor out; any device) ------------------------------------------
+    def g2(self, t):
+        return self.beta_start + (self.beta_end - self.beta_start) * t
+
+    def f(self, t):
+        return -0.5 * self.g2(t)
+
+    def var(self, t):
+        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
+            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+
+    def e2int_f(self, t):
+        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
+
+    def discrete(self, idx):
+        return self.betas.index_select(0, idx), self.alpha.index_select(0, idx)
+
+
+class DiffusionSubVPSDE(DiffusionBase):
+    """diffusion_continuous.py:681-729: the sub-VP SDE (same drift as the VP-SDE, g2 = beta (1 - exp(-2 int beta))).  It has
+    no `betas` table upstream either: the 'ancestral' / 'ddim' predictors raise the reference's AttributeError."""
+    score_kind = 1
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.beta_start = args.beta_start
+        self.beta_end = args.beta_end
+
+    def score_consts(self):
+        return self.beta_start, self.beta_end, self.sigma2_0
+
+    def beta(self, t):
+        return self.beta_start + (self.beta_end - self.beta_start) * t
+
+    def f(self, t):
+        return -0.5 * self.beta(t)
+
+    def g2(self, t):
+        return self.beta(t) * (1.0 - torch.exp(-2.0 * self.beta_start * t - (self.beta_end - self.beta_start) * t * t))
+
+    def var(self, t):
+        int_term = torch.exp(-self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+        return torch.square(1.0 - int_term) + self.sigma2_0 * int_term
+
+    def e2int_f(self, t):
+        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
+
+    def var_vpsde(self, t):
+        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
+            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+
+    def inv_var_vpsde(self, var):
+        c = torch.log((1 - var) / (1 - self.sigma2_0))
+        a = self.beta_end - self.beta_start
+        return (-self.beta_start + torch.sqrt(np.square(self.beta_start) - 2 * a * c)) / a
+
+
+class _GeometricVariance(DiffusionBase):
+    """var(t) = sigma2_min (sigma2_max / sigma2_min)^t - sigma2_min + sigma2_0, shared by the VE and the geometric SDE."""
+    score_kind = 2
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.sigma2_min = args.sigma2_min
+        self.sigma2_max = args.sigma2_max
+
+    def score_consts(self):
+        return self.sigma2_min, self.sigma2_max / self.sigma2_min, self.sigma2_0
+
+    def var(self, t):
+        return self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t) - self.sigma2_min + self.sigma2_0
+
+    def inv_var(self, var):
+        return torch.log((var + self.sigma2_min - self.sigma2_0) / self.sigma2_min) / np.log(
+            self.sigma2_max / self.sigma2_min)
+
+
+class DiffusionVESDE(_GeometricVariance):
+    """diffusion_continuous.py:732-766: dz = sqrt(beta(t)) dW."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        assert self.sigma2_min == self.sigma2_0, "VESDE was proposed implicitly assuming sigma2_min = sigma2_0!"
+
+    def f(self, t):
+        return torch.zeros_like(t)
+
+    def g2(self, t):
+        return self.sigma2_min * np.log(self.sigma2_max / self.sigma2_min) * ((self.sigma2_max / self.sigma2_min) ** t)
+
+    def e2int_f(self, t):
+        return torch.ones_like(t)
+
+    def var_N(self, t):
+        return 1.0 - self.sigma2_min + self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t)
+
+    def inv_var_N(self, var):
+        return torch.log((var + self.sigma2_min - 1.0) / self.sigma2_min) / np.log(self.sigma2_max / self.sigma2_min)
+
+
+class DiffusionGeometric(_GeometricVariance):
+    """diffusion_continuous.py:595-623: the VP drift with a geometric progression of the variance."""
+
+    def f(self, t):
+        return -0.5 * self.g2(t)
+
+    def g2(self, t):
+        sigma2_geom = self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t)
+        log_term = np.log(self.sigma2_max / self.sigma2_min)
+        return sigma2_geom * log_term / (1.0 - self.sigma2_0 + self.sigma2_min - sigma2_geom)
+
+    def e2int_f(self, t):
+        return torch.sqrt(
+            1.0 + self.sigma2_min * (1.0 - (self.sigma2_max / self.sigma2_min) ** t) / (1.0 - self.sigma2_0))
 
 
 def langevin_update(x, params, z, x_mean, std_t, snr, n_total, n_valid, sharded, scratch):

@@ -225,6 +225,18 @@ def vpsde_score(params, t, beta0, beta1, sigma2_0):
     return out
 
 
+def sde_score(params, t, kind, c0, c1, c2):
+    """-params / sqrt(var(t)) for the SDE family `kind` (0 vpsde, 1 sub_vpsde, 2 vesde / geometric_sde; constants as in
+    include/ldt_hip.h): params fp32 [B, ...], t fp32 [B]."""
+    _need(params, torch.float32, "params"); _need(t, torch.float32, "t")
+    params, t = params.contiguous(), t.contiguous()
+    out = torch.empty_like(params)
+    B = params.shape[0]
+    check(lib().ldt_sde_score(_p(params), _p(t), int(kind), float(c0), float(c1), float(c2), _p(out), B, params.numel() // B,
+                              stream_ptr()), "ldt_sde_score")
+    return out
+
+
 def add_f32(a, b, out=None):
     """a + b, fp32, same shape."""
     _need(a, torch.float32, "a"); _need(b, torch.float32, "b")

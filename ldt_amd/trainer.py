@@ -14,7 +14,7 @@ import time
 import torch
 
 from . import dist as ldist
-from .diffusion import DiffusionVPSDE
+from .diffusion import DiffusionSubVPSDE, DiffusionVESDE, DiffusionVPSDE
 
 
 class EMAWeights:
@@ -53,9 +53,12 @@ class EMAWeights:
 class Trainer:
     def __init__(self, cfg, model, compressor, device):
         self.cfg = cfg
-        if cfg.sde.sde_type != "vpsde":
-            raise NotImplementedError("sde_type %r: only 'vpsde' is on the shipped path" % cfg.sde.sde_type)
-        self.SDE = DiffusionVPSDE(cfg.sde)
+        if cfg.sde.sde_type == "vpsde":                   # Latent_SDE_Trainer.py:23-28 (any other type leaves no self.SDE upstream)
+            self.SDE = DiffusionVPSDE(cfg.sde)
+        elif cfg.sde.sde_type == "sub_vpsde":
+            self.SDE = DiffusionSubVPSDE(cfg.sde)
+        elif cfg.sde.sde_type == "vesde":
+            self.SDE = DiffusionVESDE(cfg.sde)
         self.sde_type = cfg.sde.sde_type
         self.num_points = cfg.data.tr_max_sample_points
         self.device = device
@@ -73,7 +76,9 @@ class Trainer:
         params = self.model(x, t, label=label, condition=condition)
         from . import ops
         sde = self.SDE                                    # score = -params / sqrt(var(t)), one HIP kernel
-        return ops.vpsde_score(params, t.float(), sde.beta_start, sde.beta_end, sde.sigma2_0), params
+        if sde.score_kind == 0:
+            return ops.vpsde_score(params, t.float(), sde.beta_start, sde.beta_end, sde.sigma2_0), params
+        return ops.sde_score(params, t.float(), sde.score_kind, *sde.score_consts()), params
 
     @torch.no_grad()
     def sample(self, num_samples, num_points=None, label=None, condition=None, *, x0=None, noise=None, seed=None,

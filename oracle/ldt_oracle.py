@@ -206,6 +206,90 @@ class VPSDE:
         return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
 
 
+class SubVPSDE:
+    """diffusion/diffusion_continuous.py:681-729 (DiffusionSubVPSDE); no betas table (ancestral / ddim raise AttributeError upstream too)."""
+
+    def __init__(self, sde_cfg):
+        self.beta_start = sde_cfg.beta_start
+        self.beta_end = sde_cfg.beta_end
+        self.sigma2_0 = sde_cfg.sigma2_0
+
+    def beta(self, t):  # :715-717
+        return self.beta_start + (self.beta_end - self.beta_start) * t
+
+    def f(self, t):  # :699-700
+        return -0.5 * self.beta(t)
+
+    def g2(self, t):  # :702-703
+        return self.beta(t) * (1.0 - torch.exp(-2.0 * self.beta_start * t - (self.beta_end - self.beta_start) * t * t))
+
+    def var(self, t):  # :705-707
+        int_term = torch.exp(-self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
+        return torch.square(1.0 - int_term) + self.sigma2_0 * int_term
+
+    def std(self, t):
+        return torch.sqrt(self.var(t))
+
+    def e2int_f(self, t):  # :709-710
+        return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
+
+
+class VESDE:
+    """diffusion/diffusion_continuous.py:732-766 (DiffusionVESDE): dz = sqrt(beta(t)) dW."""
+
+    def __init__(self, sde_cfg):
+        self.sigma2_min = sde_cfg.sigma2_min
+        self.sigma2_max = sde_cfg.sigma2_max
+        self.sigma2_0 = sde_cfg.sigma2_0
+        assert self.sigma2_min == self.sigma2_0                      # :741
+
+    def f(self, t):  # :743-744
+        return torch.zeros_like(t)
+
+    def g2(self, t):  # :746-747
+        return self.sigma2_min * np.log(self.sigma2_max / self.sigma2_min) * ((self.sigma2_max / self.sigma2_min) ** t)
+
+    def var(self, t):  # :749-750
+        return self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t) - self.sigma2_min + self.sigma2_0
+
+    def std(self, t):
+        return torch.sqrt(self.var(t))
+
+    def e2int_f(self, t):  # :752-753
+        return torch.ones_like(t)
+
+
+class GeometricSDE:
+    """diffusion/diffusion_continuous.py:595-623 (DiffusionGeometric): VP drift, geometric progression of the variance."""
+
+    def __init__(self, sde_cfg):
+        self.sigma2_min = sde_cfg.sigma2_min
+        self.sigma2_max = sde_cfg.sigma2_max
+        self.sigma2_0 = sde_cfg.sigma2_0
+
+    def f(self, t):  # :606-607
+        return -0.5 * self.g2(t)
+
+    def g2(self, t):  # :609-612
+        sigma2_geom = self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t)
+        log_term = np.log(self.sigma2_max / self.sigma2_min)
+        return sigma2_geom * log_term / (1.0 - self.sigma2_0 + self.sigma2_min - sigma2_geom)
+
+    def var(self, t):  # :614-615
+        return self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t) - self.sigma2_min + self.sigma2_0
+
+    def std(self, t):
+        return torch.sqrt(self.var(t))
+
+    def e2int_f(self, t):  # :617-619
+        return torch.sqrt(1.0 + self.sigma2_min * (1.0 - (self.sigma2_max / self.sigma2_min) ** t) / (1.0 - self.sigma2_0))
+
+
+def make_sde(sde_cfg):
+    """diffusion/diffusion_continuous.py:18-29 (make_diffusion)."""
+    return {"vpsde": VPSDE, "sub_vpsde": SubVPSDE, "vesde": VESDE, "geometric_sde": GeometricSDE}[sde_cfg.sde_type](sde_cfg)
+
+
 def score_fn_from_model(sde, model_fn):
     """trainer/Latent_SDE_Trainer.py:57-61: params -> (score, params)."""
     def fn(t, x):

@@ -214,6 +214,46 @@ def test_other_predictors_golden(env, pred):
     assert rel_mse(out.cpu(), a[pred]) < TOL_LATENT
 
 
+@pytest.mark.parametrize("name", ["sub_vpsde", "vesde", "geometric_sde"])
+def test_other_sde_families_golden(env, name):
+    """The sub-VP, VE and geometric SDEs (diffusion_continuous.py:595-623, :681-766) through the generic predictors vs the
+    reference's own sample_discrete (tests/golden/sde_types.npz).  sub_vpsde / vesde go through Trainer (its sde_type dispatch,
+    Latent_SDE_Trainer.py:23-28, stock score_fn -> fused loop); geometric_sde, which upstream's Trainer cannot build either, through
+    make_diffusion and a caller-side score_fn (python-driven loop, ldt_sde_score)."""
+    import copy
+    ldt, tg, tiny = env["ldt"], env["tg"], env["cfg"]
+    a, _ = load_golden("sde_types")
+    cfg = copy.deepcopy(tiny)
+    cfg.sde.sde_type = name
+    for k in ("sigma2_min", "sigma2_max", "sigma2_0"):
+        if "%s/%s" % (name, k) in a:
+            setattr(cfg.sde, k, float(a["%s/%s" % (name, k)]))
+    if name == "geometric_sde":
+        sde = ldt.make_diffusion(cfg.sde)
+        score = env["score"]
+
+        def score_fn(t, x, label=None, condition=None):
+            params = score(x, t, label=label, condition=condition)
+            return ldt.ops.sde_score(params, t.float(), sde.score_kind, *sde.score_consts()), params
+    else:
+        tr = ldt.Trainer(cfg, env["score"], env["comp"], "cuda:0")
+        sde, score_fn = tr.SDE, tr.score_fn
+    # the score half of score_fn against the reference's formula on the host
+    t = torch.tensor([1.0, 0.37], device="cuda:0")
+    sc, params = score_fn(t, tg["x0"].cuda())
+    want = -params.cpu() / torch.sqrt(sde.var(t.cpu()))[:, None, None]
+    assert rel_mse(sc.cpu(), want) < 1e-12
+    for pred, pf in (("reversediffusion", False), ("eulermaruyama", False), ("reversediffusion", True)):
+        out = sde.sample_discrete(score_fn=score_fn, num_samples=2, N=cfg.sde.sample_N, predictor=pred, corrector=None, corrector_steps=1,
+                                  shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=pf,
+                                  denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"])
+        assert rel_mse(out.cpu(), a["%s/%s%s" % (name, pred, "_pf" if pf else "")]) < TOL_LATENT, (name, pred, pf)
+    with pytest.raises(AttributeError):                                      # no betas table outside the VP-SDE, as upstream
+        sde.sample_discrete(score_fn=score_fn, num_samples=2, N=cfg.sde.sample_N, predictor="ancestral", corrector=None, corrector_steps=1,
+                            shape=(cfg.score.z_scale, cfg.score.z_dim), time_eps=cfg.sde.sample_time_eps, probability_flow=False,
+                            denoise=True, snr=0.01, device="cuda:0", x0=tg["x0"], noise=tg["noises"])
+
+
 def test_ancestral_corrector_and_print_steps_golden(env):
     """predictor + AncestralCorrector (2 corrector steps) and the print_steps trajectory dump vs the reference."""
     a, _ = load_golden("sampler_extras")

@@ -50,6 +50,46 @@ def test_vpsde_tables_and_step_table(tiny_cfg):
         sde.step_table(10, "bogus", 1e-6)
 
 
+def _sde_cfg(tiny_cfg, name, a):
+    import copy
+    c = copy.deepcopy(tiny_cfg.sde)
+    c.sde_type = name
+    for k in ("sigma2_min", "sigma2_max", "sigma2_0"):
+        if "%s/%s" % (name, k) in a:
+            setattr(c, k, float(a["%s/%s" % (name, k)]))
+    return c
+
+
+def test_other_sde_families_schedules_match_reference(tiny_cfg):
+    """make_diffusion dispatch (diffusion_continuous.py:18-29) and f / g2 / var / e2int_f of the sub-VP, VE and geometric SDEs
+    against values captured from the reference (tests/golden/sde_types.npz); the oracle's restatement against the same."""
+    import ldt_amd
+    from ldt_amd import diffusion as D
+    from oracle import ldt_oracle as O
+    a, _ = load_golden("sde_types")
+    classes = {"sub_vpsde": D.DiffusionSubVPSDE, "vesde": D.DiffusionVESDE, "geometric_sde": D.DiffusionGeometric}
+    for name, cls in classes.items():
+        c = _sde_cfg(tiny_cfg, name, a)
+        sde = ldt_amd.make_diffusion(c)
+        osde = O.make_sde(c)
+        assert type(sde) is cls and sde.sde_type == name
+        for fn in ("f", "g2", "var", "e2int_f"):
+            assert torch.equal(getattr(sde, fn)(a["probe_t"]), a["%s/%s" % (name, fn)]), (name, fn)
+            assert torch.equal(getattr(osde, fn)(a["probe_t"]), a["%s/%s" % (name, fn)]), (name, fn)
+        ts, coef, mode = sde.step_table(50, "reversediffusion", 1e-6)
+        assert mode == 1 and torch.isfinite(coef).all()
+        with pytest.raises(AttributeError):                                  # no betas table outside the VP-SDE, as upstream
+            sde.step_table(50, "ancestral", 1e-6)
+    assert type(ldt_amd.make_diffusion(tiny_cfg.sde)) is D.DiffusionVPSDE
+    bad = _sde_cfg(tiny_cfg, "bogus", a)
+    with pytest.raises(ValueError, match="Unrecognized sde type"):
+        ldt_amd.make_diffusion(bad)
+    ve = _sde_cfg(tiny_cfg, "vesde", a)
+    ve.sigma2_0 = 0.5
+    with pytest.raises(AssertionError):                                      # :741
+        ldt_amd.make_diffusion(ve)
+
+
 def test_folded_predictor_coefficients_match_oracle_math(tiny_cfg):
     """x_mean = A x + B params, x = x_mean + C z reproduces the oracle's (reference's) update for one step."""
     import ldt_amd

@@ -152,6 +152,25 @@ def test_other_predictors(tiny_cfg):
         assert rel_mse(out, a[pred]) < 1e-8, pred
 
 
+def test_other_sde_families(tiny_cfg):
+    """sub-VP, VE and geometric SDE through the generic predictors vs the reference's own sample_discrete (sde_types.npz)."""
+    import copy
+    a, _ = load_golden("sde_types")
+    t, _ = load_golden("trainer_sample_tiny")
+    score_sd = load_golden("score_tiny")[1]["w"]
+    for name in ("sub_vpsde", "vesde", "geometric_sde"):
+        c = copy.deepcopy(tiny_cfg.sde)
+        c.sde_type = name
+        for k in ("sigma2_min", "sigma2_max", "sigma2_0"):
+            if "%s/%s" % (name, k) in a:
+                setattr(c, k, float(a["%s/%s" % (name, k)]))
+        sde = O.make_sde(c)
+        fn = O.score_fn_from_model(sde, lambda x, tt: O.score_forward(score_sd, tiny_cfg.score, x, tt))
+        for pred, pf in (("reversediffusion", False), ("eulermaruyama", False), ("reversediffusion", True)):
+            out = O.sample_discrete(sde, fn, t["x0"], list(t["noises"]), tiny_cfg.sde.sample_N, predictor=pred, probability_flow=pf)
+            assert rel_mse(out, a["%s/%s%s" % (name, pred, "_pf" if pf else "")]) < 1e-8, (name, pred, pf)
+
+
 def test_corrector_and_print_steps(tiny_cfg):
     a, _ = load_golden("sampler_extras")
     score_sd = load_golden("score_tiny")[1]["w"]
