@@ -44,8 +44,11 @@ class Score(nn.Module):
         if self.condition:
             from .condition import ConditionNet                     # built first, as upstream (score.py:64-65)
             self.c_net = ConditionNet(self.hidden_size, self.t_dim, patch_size=self.z_scale)
-        if not self.AdaLN or getattr(cfg, "dropout", 0.):
-            raise NotImplementedError("only AdaLN blocks without dropout are built")
+        # dropout (score.py:61; layers.py:179,199,129) is the identity under eval(), the only mode the sampling path runs in
+        # (Latent_SDE_Trainer.py:144): it is accepted and checked against self.training in forward
+        self.dropout = float(getattr(cfg, "dropout", 0.) or 0.)
+        if not self.AdaLN:
+            raise NotImplementedError("AdaLN: False blocks (layers.py:221-223) are not built — no shipped YAML sets it")
         if self.num_blocks > MAX_BLOCKS:
             raise ValueError("num_blocks > %d" % MAX_BLOCKS)
         D = self.hidden_size
@@ -350,6 +353,8 @@ class Score(nn.Module):
         (cfg.score.condition=True) first, as upstream (:129-131)."""
         if not x.is_cuda:
             raise RuntimeError("Score.forward: x is on %s; the HIP path has no CPU fallback" % x.device)
+        if self.training and self.dropout > 0:
+            raise RuntimeError("Score.forward: dropout=%g needs eval() — the HIP path is the inference (sampling) path" % self.dropout)
         B, T, z = x.shape
         assert z == self.z_dim
         x = x.contiguous().float()

@@ -50,6 +50,20 @@ def test_vpsde_tables_and_step_table(tiny_cfg):
         sde.step_table(10, "bogus", 1e-6)
 
 
+def test_score_block_variant_guards(tiny_cfg):
+    """dropout > 0 is accepted (identity under eval(), the sampling mode) and refused in training mode at forward time;
+    AdaLN: False — set by no shipped YAML — is refused at construction with a message naming it."""
+    import copy
+    import ldt_amd
+    c = copy.deepcopy(tiny_cfg.score)
+    c.dropout = 0.1
+    m = ldt_amd.Score(c)
+    assert m.dropout == 0.1
+    c.AdaLN = False
+    with pytest.raises(NotImplementedError, match="AdaLN: False"):
+        ldt_amd.Score(c)
+
+
 def _sde_cfg(tiny_cfg, name, a):
     import copy
     c = copy.deepcopy(tiny_cfg.sde)
