@@ -131,6 +131,81 @@ __device__ __forceinline__ void attn_tile(const char* Kt, const char* Vt, const 
     attn_block<DH>(Kt, Vt, 1, qf, oacc, m_run, l_run, kv0, Nk, hh, c, lo);
 }
 
+// The 64-key tile as ONE online-softmax step (whole-head kernel): both 32-key blocks' S^T chains are issued interleaved (two
+// independent accumulators: the second chain runs in the first one's MFMA latency), one row maximum / one defer-max test per
+// tile, 32 exponentials with no dependence between them, then the four 16-key slices of O^T += V^T P^T.  attn_block's
+// per-wave dependency chain (LDS read -> 4 dependent MFMAs -> max -> exp -> cvt -> MFMAs, twice per tile) is what bounds the
+// other two kernels at 4 waves per SIMD (tools/dbg/attn_ablate.sh: 26.7 us with the loads compiled out, 23.4 us with the
+// compute compiled out, 35.9 us together); here the chain per tile is less than half as long.
+template <int DH>
+__device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
+                                                float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
+                                                const AttnLaneOffs<DH>& lo) {
+    constexpr int ROWB = DH * 2, ND = DH / 32, NS = DH / 16;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(Kt + (lo.k0 ^ (s << 5)));
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(Kt + 32 * ROWB + (lo.k0 ^ (s << 5)));
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    if (kv0 + 64 > Nk) {                                             // ragged tile: mask keys >= Nk
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = kv0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            s0[i] = (key < Nk) ? s0[i] : -INFINITY;
+            s1[i] = (key + 32 < Nk) ? s1[i] : -INFINITY;
+        }
+    }
+    float mx = __builtin_fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[i]), s1[i]);   // -> v_max3_f32
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (__builtin_amdgcn_ballot_w64((mx - m_run) * c > ATT_THR) != 0) {   // wave-uniform; always on the first tile (m_run = -inf)
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
+        m_run = m_new;
+        const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 o = {oacc[d][i], oacc[d][i + 1]};
+                o *= a2;                                             // v_pk_mul_f32
+                oacc[d][i] = o[0]; oacc[d][i + 1] = o[1];
+            }
+    }
+    const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
+    f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
+    bf16x8 pf[4];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 ea = (f32x2){s0[i], s0[i + 1]} * c2 + nmc2;      // v_pk_fma_f32
+        const f32x2 eb = (f32x2){s1[i], s1[i + 1]} * c2 + nmc2;
+        f32x2 pa, pb;
+        pa[0] = __builtin_amdgcn_exp2f(ea[0]); pa[1] = __builtin_amdgcn_exp2f(ea[1]);
+        pb[0] = __builtin_amdgcn_exp2f(eb[0]); pb[1] = __builtin_amdgcn_exp2f(eb[1]);
+        psa += pa; psb += pb;                                        // v_pk_add_f32
+        pf[i >> 3][i & 7] = (bf16_t)pa[0];       pf[i >> 3][(i & 7) + 1] = (bf16_t)pa[1];
+        pf[2 + (i >> 3)][i & 7] = (bf16_t)pb[0]; pf[2 + (i >> 3)][(i & 7) + 1] = (bf16_t)pb[1];
+    }
+    l_run += (psa[0] + psa[1]) + (psb[0] + psb[1]);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)                                   // 16-key slices: block s2 >> 1, half s2 & 1
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const char* base = Vt + 16 * s2 * ROWB;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + lo.v[d]));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(base + 8 * ROWB + lo.v[d]));
+            const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[d], 0, 0, 0);
+        }
+}
+
 template <int DH, bool OPROJ = false>
 __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                      // keys per LDS tile
@@ -425,6 +500,113 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
 }
 
 // -------------------------------------------------------------------------------------------------
+// Whole-head form for the Score's self-attention at 129..256 tokens (Dh = 64: T = 256, the headline shape): one workgroup of EIGHT
+// waves per (b,h), every query row of the head in flight at once (wave w owns rows 32 w ..).  All of the head's K and V rows go to
+// LDS by LDS-DMA (1-KiB pieces, swizzle applied on the source address), the wave's Q fragments are requested right behind them, and
+// ONE wait covers the lot: a workgroup pays one memory round trip, then runs its four key tiles without a barrier, then stages its
+// output rows through the (now free) K region.  The streaming kernel pays a round trip per 64-key tile behind a barrier (its tile
+// compute, ~0.8 us, is shorter than the load it is supposed to hide), the 4-wave resident kernel two register-staged load rounds
+// plus a Q round trip per query block.  64 KiB of LDS and <= 128 VGPRs: two workgroups (16 waves) per CU.  Same math, same layouts,
+// the tile is one online-softmax step (attn_tile_joint): results agree with the other two kernels to rounding, not bit for bit.
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_fwd_head_kernel(const AttnArgs a, int ntl) {
+    constexpr int KT = 64;
+    constexpr int ROWB = DH * 2;
+    constexpr int CH = ROWB / 16;
+    constexpr int NS = DH / 16;
+    constexpr int ND = DH / 32;
+    constexpr int TILE = KT * ROWB;
+    constexpr int RPP = 64 / CH;                                        // rows per 1-KiB DMA piece
+    extern __shared__ __attribute__((aligned(16))) char rsmem[];       // [K: ntl tiles][V: ntl tiles]; later the 8 waves' output rows
+    char* Ks = rsmem;
+    char* Vs = rsmem + ntl * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.x;
+    const int b = bh / a.H, head = bh % a.H;
+    const bf16_t* Qb = a.Q + (long)b * a.q_batch_stride + head * DH;
+    const bf16_t* Kb = a.K + (long)b * a.kv_batch_stride + head * DH;
+    const bf16_t* Vb = a.V + (long)b * a.kv_batch_stride + head * DH;
+    {
+        const int npieces = ntl * KT / RPP;
+        const int lr = lane / CH, cd = lane % CH;
+#ifdef ATT_DBG_NOLOAD
+        for (int p = wave; p < 0; p += 8) {
+#else
+        for (int p = wave; p < npieces; p += 8) {
+#endif
+            const int row = p * RPP + lr;
+            const int krow = row < a.Nk ? row : a.Nk - 1;               // rows past Nk: P is exactly 0 there
+            const int sk = (DH == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+            const int sv = (DH == 64) ? (((row >> 1) & 1) << 2) : 0;
+            const bf16_t* ks = Kb + (long)krow * a.ldk + ((cd ^ sk) << 3);
+            const bf16_t* vs = Vb + (long)krow * a.ldv + ((cd ^ sv) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                             (__attribute__((address_space(3))) void*)(Ks + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                             (__attribute__((address_space(3))) void*)(Vs + p * 1024), 16, 0, 0);
+        }
+    }
+    const int q0 = wave * 32;
+    const bool active = q0 < a.Nq;                                      // wave-uniform
+    bf16x8 qf[NS];
+    if (active) {
+        int qrow = q0 + r;
+        qrow = qrow < a.Nq ? qrow : a.Nq - 1;
+        const bf16_t* qp = Qb + (long)qrow * a.ldq + 8 * hh;
+#pragma unroll
+#ifdef ATT_DBG_NOLOAD
+        for (int s = 0; s < NS; ++s) qf[s] = (bf16x8){(bf16_t)(float)lane, 1, 1, 1, 1, 1, 1, 1};
+        (void)qp;
+#else
+        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 oacc[ND];
+    float m_run = -INFINITY, l_run = 0.f;
+    if (active) {
+        const float c = a.scale_log2e;
+        AttnLaneOffs<DH> lo;
+        lo.init(lane);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+#ifdef ATT_DBG_NOCOMPUTE
+        for (int t = 0; t < ntl; ++t) { l_run += (float)qf[t & (NS - 1)][0]; (void)c; }
+#else
+        for (int t = 0; t < ntl; ++t)
+            attn_tile_joint<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+#endif
+    }
+    __syncthreads();                                                    // every wave is done with K and V: their LDS becomes the output stage
+    if (!active) return;
+    char* ost = rsmem + wave * (32 * ROWB);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chn = d * 4 + g;                                  // 16-B chunk; hh picks its 8-B half
+            const bf16x4 pk = {(bf16_t)(oacc[d][4 * g + 0] * inv), (bf16_t)(oacc[d][4 * g + 1] * inv),
+                               (bf16_t)(oacc[d][4 * g + 2] * inv), (bf16_t)(oacc[d][4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(ost + r * ROWB + ((chn ^ (r & (CH - 1))) << 4) + hh * 8) = pk;
+        }
+    bf16_t* ob = a.O + (((long)b * a.H + head) * a.Nq + q0) * DH;
+#pragma unroll
+    for (int it = 0; it < (32 * CH) / 64; ++it) {
+        const int row = it * (64 / CH) + lane / CH, ch = lane % CH;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ost + row * ROWB + ((ch ^ (row & (CH - 1))) << 4));
+        if (q0 + row < a.Nq) *reinterpret_cast<bf16x8*>(ob + (long)row * DH + ch * 8) = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Resident form of the fused attention + output projection + residual (narrow blocks, Dh = 32) for cross-attention from many
 // queries to few keys — the Compressor's decoder levels: 2048 point queries x T <= 512 token keys per cloud.  The streaming kernel
 // above gives every 128-query block a workgroup of its own, and each of them re-reads the head's K/V (32 KB) and all of Wo (32 KB)
@@ -566,6 +748,16 @@ static int launch_resident(const AttnArgs* a, hipStream_t s) {
     return ldt_check_launch("attn_fwd_resident");
 }
 
+template <int DH>
+static int launch_head(const AttnArgs* a, hipStream_t s) {
+    const int ntl = (a->Nk + 63) / 64;
+    size_t lds = (size_t)2 * ntl * 64 * DH * 2;
+    if (lds < (size_t)8 * 32 * DH * 2) lds = (size_t)8 * 32 * DH * 2;
+    LDT_ENSURE_LDS(&attn_fwd_head_kernel<DH>, 65536, "attention");
+    hipLaunchKernelGGL(attn_fwd_head_kernel<DH>, dim3((unsigned)(a->B * a->H)), dim3(512), lds, s, *a, ntl);
+    return ldt_check_launch("attn_fwd_head");
+}
+
 int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s) {
     LDT_REQUIRE(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, LDT_ESHAPE, "attention_oproj: empty problem");
     LDT_REQUIRE(dh == 32 && (a->H == 2 || a->H == 4), LDT_ESHAPE,
@@ -610,6 +802,8 @@ int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s) {
     static const int force = getenv("LDT_ATTN_FORCE") ? atoi(getenv("LDT_ATTN_FORCE")) : 0;   // 1 stream, 2 resident (tools/dbg)
     const bool fits = (long)a->Nk * dh <= 256 * 64;
     if (fits && (force == 2 || (force == 0 && a->Nq <= 128))) return dh == 64 ? launch_resident<64>(a, s) : launch_resident<32>(a, s);
+    // 129..256 queries of a Dh = 64 head (the Score at T = 256): the whole-head 8-wave kernel
+    if (fits && dh == 64 && a->Nq <= 256 && (long)a->B * a->H < (1L << 31) && (force == 3 || (force == 0 && a->Nq > 128))) return launch_head<64>(a, s);
     const long nqb = (a->Nq + 127) / 128, groups = ((long)a->B * a->H + 7) / 8;
     LDT_REQUIRE(groups * 8 * nqb < (1L << 31), LDT_ESHAPE, "attention: grid too large");
     dim3 grid((unsigned)(groups * 8 * nqb)), block(256);

@@ -28,13 +28,13 @@
 
 #define BK 64
 
-template <int ROWS>
+template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
                                            int k0, char* lds_tile, int wave, int lane) {
-    // one operand tile = ROWS rows x 128 B = ROWS/8 pieces of 1 KiB (8 rows each); ROWS/32 pieces per wave
+    // one operand tile = ROWS rows x 128 B = ROWS/8 pieces of 1 KiB (8 rows each); ROWS/(8 NW) pieces per wave
 #pragma unroll
-    for (int p = 0; p < ROWS / 32; ++p) {
-        const int piece = wave * (ROWS / 32) + p;
+    for (int p = 0; p < ROWS / (8 * NW); ++p) {
+        const int piece = wave * (ROWS / (8 * NW)) + p;
         const int r = piece * 8 + (lane >> 3);
         const int cdst = lane & 7;
         const int csrc = cdst ^ ((r >> 1) & 7);
@@ -52,12 +52,16 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
 // NST = 2: a stage is waited for in full before the barrier (the simple 2-phase loop).  NST = 3: the DMA of stage
 // kt+2 stays in flight across the barrier (counted vmcnt, raw s_barrier), which hides the load latency when only 1-3
 // workgroups share a CU (small M: the T = 32 latents, half-batch shapes).
-template <int EPI, int TBM, int TBN, int NST = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
+// NW = 8 (512 threads, waves 4 x 2 over the tile): the mid-size form — a 256 x 128 tile with a 3-stage ring is ONE workgroup per CU
+// whose operand stream carries 85 flop per byte (128 x 64 tiles: 43), for the batches whose GEMMs are bound by the per-CU
+// L2 -> LDS rate (M = 1-4 k rows; DESIGN.md §4 "small-batch regime").
+template <int EPI, int TBM, int TBN, int NST = 2, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a) {
     constexpr int BM = TBM, BN = TBN;
     constexpr int XB = TBM * BK * 2, WB = TBN * BK * 2;               // operand tile bytes per stage
-    constexpr int MT = TBM / 32, NT = TBN / 32;                       // 16x16 accumulator tiles per wave (m, n)
-    constexpr int OPS = TBM / 32 + TBN / 32;                          // LDS-DMA instructions per wave and stage
+    constexpr int WGM = NW / 2;                                       // waves along m (2 along n)
+    constexpr int MT = TBM / (16 * WGM), NT = TBN / 32;               // 16x16 accumulator tiles per wave (m, n)
+    constexpr int OPS = (TBM + TBN) / (8 * NW);                       // LDS-DMA instructions per wave and stage
     __shared__ __attribute__((aligned(16))) char smem[NST * (XB + WB)];  // [stage][X|W]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tile_m = wgid / tiles_n, tile_n = wgid % tiles_n;
+    // tile order: row-major (an XCD's chunk of workgroups = a band of output rows x every column tile: it reads its own rows of X
+    // and ALL of W) or, a.dbg bit 4, column-major (a band of column tiles x every row tile: its own slice of W, all of X)
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tile_m = (a.dbg & 16) ? wgid % tiles_m : wgid / tiles_n, tile_n = (a.dbg & 16) ? wgid / tiles_m : wgid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x4 acc[NT][MT];
@@ -85,15 +92,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     const bf16_t* Xk = a.X + kbase;
     const bf16_t* Wk = a.W + kbase;
     const int nk = ksplit / BK;
-    stage_tile<TBM>(Xk, a.ldx, m0, a.M, 0, smem, wave, lane);
-    stage_tile<TBN>(Wk, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
+    stage_tile<TBM, NW>(Xk, a.ldx, m0, a.M, 0, smem, wave, lane);
+    stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
     // stages 1 .. NST-2 follow at once; wait until only they are outstanding (stage 0 landed)
     int ahead = 0;                                                    // stages issued beyond the one being waited for
 #pragma unroll
     for (int st = 1; st < NST - 1; ++st)
         if (st < nk) {
-            stage_tile<TBM>(Xk, a.ldx, m0, a.M, st * BK, smem + st * (XB + WB), wave, lane);
-            stage_tile<TBN>(Wk, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
+            stage_tile<TBM, NW>(Xk, a.ldx, m0, a.M, st * BK, smem + st * (XB + WB), wave, lane);
+            stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
             ++ahead;
         }
     if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
         if (kt + NST - 1 < nk) {                                      // buffer of stage kt-1 (NST = 3) / kt+1's own (NST = 2)
             int nb = cur + NST - 1; nb = nb >= NST ? nb - NST : nb;
             char* nx = smem + nb * (XB + WB);
-            stage_tile<TBM>(Xk, a.ldx, m0, a.M, (kt + NST - 1) * BK, nx, wave, lane);
-            stage_tile<TBN>(Wk, a.ldw, n0, a.N, (kt + NST - 1) * BK, nx + XB, wave, lane);
+            stage_tile<TBM, NW>(Xk, a.ldx, m0, a.M, (kt + NST - 1) * BK, nx, wave, lane);
+            stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, (kt + NST - 1) * BK, nx + XB, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int rx = wm * (TBM / 2) + i * 16 + lrow;
+                const int rx = wm * (TBM / WGM) + i * 16 + lrow;
                 xf[i] = *reinterpret_cast<const bf16x8*>(sx + rx * 128 + ((c ^ ((rx >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const GemmArgs a) {
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int m = m0 + wm * (TBM / 2) + mi * 16 + lrow;
+        const int m = m0 + wm * (TBM / WGM) + mi * 16 + lrow;
         if (m >= a.M) continue;
         const float* grow = nullptr;
         if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
@@ -1160,7 +1167,9 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
         static const int sk_shape = getenv("LDT_GEMM_SPLITK_SHAPE") ? atoi(getenv("LDT_GEMM_SPLITK_SHAPE")) : -1;   // tools/dbg
         const int shape = sk_shape >= 0 ? sk_shape : (nt(128, 128) * a->splits >= 2 * LDT_NUM_CUS) ? 0 : (nt(128, 64) * a->splits >= 2 * LDT_NUM_CUS ? 1 : 2);
         dim3 block(256);
-        if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), block, 0, stream, *a);
+        if (shape == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 256, 128, 3, 8>), dim3((unsigned)nt(256, 128), (unsigned)a->splits), dim3(512), 0, stream, *a);
+        else if (shape == 4) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128, 4, 8>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), dim3(512), 0, stream, *a);
+        else if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), block, 0, stream, *a);
         else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 64>), dim3((unsigned)nt(128, 64), (unsigned)a->splits), block, 0, stream, *a);
         else hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 64, 64, 3>), dim3((unsigned)nt(64, 64), (unsigned)a->splits), block, 0, stream, *a);
         return ldt_check_launch("gemm_bf16_nt(split-K)");
@@ -1195,9 +1204,15 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     // 31.3 us; a 4th stage measured equal): at 128x64 / 128x128 the third buffer costs a co-resident workgroup and loses 20-40 %
     static const int v1_stages_env = getenv("LDT_GEMM_V1_STAGES") ? atoi(getenv("LDT_GEMM_V1_STAGES")) : 0;   // tools/dbg
     const int v1_stages = v1_stages_env ? v1_stages_env : (shape == 2 ? 3 : 2);
+    static const int v1_map_env = getenv("LDT_GEMM_V1_MAP") ? atoi(getenv("LDT_GEMM_V1_MAP")) : 0;          // tools/dbg
+    GemmArgs a_v1 = *a;
+    a_v1.dbg = (a_v1.dbg & 15) | (v1_map_env ? 16 : 0);
+    a = &a_v1;
 #define LAUNCH_V1(E)                                                                                                     \
     do {                                                                                                                 \
-        if (v1_stages >= 3) {                                                                                            \
+        if (shape == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 256, 128, 3, 8>), dim3((unsigned)ntiles(256, 128)), dim3(512), 0, stream, *a); \
+        else if (shape == 4) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128, 4, 8>), dim3((unsigned)ntiles(128, 128)), dim3(512), 0, stream, *a); \
+        else if (v1_stages >= 3) {                                                                                       \
             if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 128, 3>), dim3((unsigned)ntiles(128, 128)), block, 0, stream, *a); \
             else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 128, 64, 3>), dim3((unsigned)ntiles(128, 64)), block, 0, stream, *a); \
             else hipLaunchKernelGGL((gemm_bf16_nt_kernel<E, 64, 64, 3>), dim3((unsigned)ntiles(64, 64)), block, 0, stream, *a);  \

@@ -184,7 +184,9 @@ def ref_attention(q, k, v, H):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,dh", [(2, 16, 256, 256, 64), (3, 4, 32, 32, 64), (2, 2, 8, 8, 64), (2, 4, 300, 77, 32),
-                                         (1, 4, 2048, 256, 32), (2, 4, 40, 2048, 32), (1, 2, 130, 512, 64), (2, 2, 8, 5, 32)])
+                                         (1, 4, 2048, 256, 32), (2, 4, 40, 2048, 32), (1, 2, 130, 512, 64), (2, 2, 8, 5, 32),
+                                         # the whole-head 8-wave kernel (Dh = 64, 129..256 queries, <= 256 keys): idle waves, ragged key tiles
+                                         (3, 16, 129, 129, 64), (2, 4, 200, 200, 64), (2, 2, 160, 256, 64), (1, 2, 256, 130, 64), (2, 2, 255, 65, 64)])
 def test_attention(B, H, Nq, Nk, dh):
     g = torch.Generator().manual_seed(Nq + Nk)
     C = H * dh
@@ -209,12 +211,13 @@ def test_attention_softmax_spike():
     assert float((out.float().cpu() - ref).abs().max()) < 0.02
 
 
-@pytest.mark.parametrize("dh,step", [(64, 2.0), (64, 5.0), (32, 3.0)])
-def test_attention_softmax_staircase(dh, step):
+@pytest.mark.parametrize("dh,step,N", [(64, 2.0, 320), (64, 5.0, 320), (32, 3.0, 320), (64, 2.0, 256), (64, 5.0, 256), (64, 7.0, 192)])
+def test_attention_softmax_staircase(dh, step, N):
     """Row maxima that keep growing along the key axis: every 32-key block raises the maximum of every query row by
     `step` (in log2 units), below and above the deferred-rescale threshold of the kernel (2^6), so both the "keep the
-    stale reference" and the "rescale" paths run many times in one row; full-tensor fp64 reference."""
-    B, H, N = 2, 2, 320
+    stale reference" and the "rescale" paths run many times in one row; full-tensor fp64 reference.  N = 320 runs the streaming
+    kernel (per 32-key block), N <= 256 at Dh = 64 the whole-head kernel (one online-softmax step per 64-key tile)."""
+    B, H = 2, 2
     C = H * dh
     g = torch.Generator().manual_seed(int(step * 10) + dh)
     q = torch.randn(B, N, C, generator=g) * 0.1; k = torch.randn(B, N, C, generator=g) * 0.1; v = torch.randn(B, N, C, generator=g)

@@ -1,8 +1,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ldt_amd
-N = 60
-cfg = ldt_amd.airplane_config(latent_tokens=256, sample_N=N)
+N = int(os.environ.get("N", 60)); T = int(os.environ.get("T", 256))
+cfg = ldt_amd.airplane_config(latent_tokens=T, sample_N=N)
 torch.manual_seed(0)
 score = ldt_amd.Score(cfg.score); comp = ldt_amd.Compressor(cfg.compressor); comp.init()
 tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
