@@ -75,9 +75,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     // tile order: row-major (an XCD's chunk of workgroups = a band of output rows x every column tile: it reads its own rows of X
-    // and ALL of W) or, a.dbg bit 4, column-major (a band of column tiles x every row tile: its own slice of W, all of X)
+    // and ALL of W) or column-major (a band of column tiles x every row tile: its own slice of W, all of X) — the launcher picks
+    // column-major for wide outputs over few row tiles (M = 1024: QKV 15.9 -> 14.5 us, MLP-up 18.2 -> 16.1 us; tools/dbg/smallm_bench.py)
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int tile_m = (a.dbg & 16) ? wgid % tiles_m : wgid / tiles_n, tile_n = (a.dbg & 16) ? wgid / tiles_m : wgid % tiles_n;
+    const int tile_m = a.col_major ? wgid % tiles_m : wgid / tiles_n, tile_n = a.col_major ? wgid / tiles_m : wgid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x4 acc[NT][MT];
@@ -1204,9 +1205,13 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     // 31.3 us; a 4th stage measured equal): at 128x64 / 128x128 the third buffer costs a co-resident workgroup and loses 20-40 %
     static const int v1_stages_env = getenv("LDT_GEMM_V1_STAGES") ? atoi(getenv("LDT_GEMM_V1_STAGES")) : 0;   // tools/dbg
     const int v1_stages = v1_stages_env ? v1_stages_env : (shape == 2 ? 3 : 2);
-    static const int v1_map_env = getenv("LDT_GEMM_V1_MAP") ? atoi(getenv("LDT_GEMM_V1_MAP")) : 0;          // tools/dbg
+    static const int v1_map_env = getenv("LDT_GEMM_V1_MAP") ? atoi(getenv("LDT_GEMM_V1_MAP")) : -1;         // tools/dbg: 0 / 1 force
     GemmArgs a_v1 = *a;
-    a_v1.dbg = (a_v1.dbg & 15) | (v1_map_env ? 16 : 0);
+    {
+        const int bm = (shape == 3) ? 256 : (shape == 2 ? 64 : 128), bn = (shape == 0 || shape == 3 || shape == 4) ? 128 : 64;
+        const long tm = (a->M + bm - 1) / bm, tn = (a->N + bn - 1) / bn;
+        a_v1.col_major = v1_map_env >= 0 ? v1_map_env : (tn >= 3 * tm ? 1 : 0);
+    }
     a = &a_v1;
 #define LAUNCH_V1(E)                                                                                                     \
     do {                                                                                                                 \

@@ -31,6 +31,7 @@ struct GemmArgs {
     int max_wgs;                        // 256-tile kernel: cap on the persistent grid (0 = one workgroup per CU); sub-batch streams use 128
     // ---- split-K (v1 kernel, EPI_F32 only): blockIdx.y = split s computes k in [s K/splits, (s+1) K/splits) into out + s * split_stride
     int splits; long split_stride;
+    int col_major;                      // v1 kernel: tile order (set by the launcher; see gemm_bf16_nt_kernel)
 };
 
 struct LnArgs {
