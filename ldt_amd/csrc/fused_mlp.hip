@@ -19,8 +19,12 @@
 //        U = GELU(U + b_up) -> bf16 -> LDS       hidden units of one row -> one 8-B LDS store)
 //        O^T[C x 32] += W_dn_c · U^T           (a lane holds 4 consecutive output channels of one row)
 //   3. epilogue from registers, 16 B per lane: the accumulators ARE the new x (no gate), or x + gate * (O + b_dn).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
+
+#define LDT_MLP_RT_DEFAULT 2          /* 16-row tiles per wave of ln_mlp_resid_kernel: 2 = 4 waves x 32 rows, 1 = 8 waves x 16 rows */
 
 namespace {
 
@@ -41,22 +45,22 @@ template <int C> struct MlpCfg {
 // the LDS-DMA source address, on plain LDS stores and on every ds_read)
 template <int CB> __device__ __forceinline__ int swz(int row) { return CB == 16 ? (row & 15) : ((row >> 1) & 7); }
 
-template <int C>
+template <int C, int NW = 4>
 __device__ __forceinline__ void stage_wup(const bf16_t* __restrict__ w_up, int hid0, char* lds, int wave, int lane) {
     constexpr int CB = MlpCfg<C>::CB, RPP = 64 / CB, PIECES = MlpCfg<C>::WUP_BYTES / 1024;    // rows per 1-KiB piece
 #pragma unroll
-    for (int p = wave; p < PIECES; p += 4) {
+    for (int p = wave; p < PIECES; p += NW) {
         const int row = p * RPP + lane / CB, phys = lane % CB;
         const bf16_t* src = w_up + (long)(hid0 + row) * C + ((phys ^ swz<CB>(row)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + p * 1024), 16, 0, 0);
     }
 }
-template <int C>
+template <int C, int NW = 4>
 __device__ __forceinline__ void stage_wdn(const bf16_t* __restrict__ w_dn, int hid0, char* lds, int wave, int lane) {
     constexpr int PIECES = MlpCfg<C>::WDN_BYTES / 1024;                                       // 8 rows of 128 B per piece
 #pragma unroll
-    for (int p = wave; p < PIECES; p += 4) {
+    for (int p = wave; p < PIECES; p += NW) {
         const int row = p * 8 + (lane >> 3), phys = lane & 7;
         const bf16_t* src = w_dn + (long)row * MlpCfg<C>::HID + hid0 + ((phys ^ swz<8>(row)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -71,13 +75,13 @@ struct LnSrc {
     const float* x; long ldx; long M;
     const float* ln_w; const float* ln_b; const float* shift; const float* scale; long mod_sample_stride; int rows_per_sample;
 };
-template <int C, bool LOAD = true>    // LOAD = false: `xv` already holds the rows (the MLP kernel's freshly updated x)
+template <int C, bool LOAD = true, int RT = 2>    // RT = 16-row tiles per wave; LOAD = false: `xv` already holds the rows (the MLP kernel's freshly updated x)
 __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char* Hs, int wave, int lrow, int lq,
-                                                 f32x4 (&xv)[C / 16][2], bf16x8 (&hf)[C / 32][2]) {
+                                                 f32x4 (&xv)[C / 16][RT], bf16x8 (&hf)[C / 32][RT]) {
     using K = MlpCfg<C>;
-    bf16x4 hpk[C / 16][2];
+    bf16x4 hpk[C / 16][RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         long grow = row0 + rt * 16 + lrow;
         grow = grow < a.M ? grow : a.M - 1;                            // tail rows: clamp, never stored
         if (LOAD) {
@@ -118,18 +122,18 @@ __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char
         }
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int n = 0; n < C / 16; ++n) {
-            const int hr = wave * 32 + rt * 16 + lrow;
+            const int hr = wave * (16 * RT) + rt * 16 + lrow;
             *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) = hpk[n][rt];
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // rows are wave-private: ordering inside the wave suffices
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int hr = wave * 32 + rt * 16 + lrow;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int hr = wave * (16 * RT) + rt * 16 + lrow;
             hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
         }
 }
@@ -137,9 +141,9 @@ __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char
 // out[rows][N] (bf16) = h . W^T + bias for the wave's 32 rows held as operand fragments `hf`; W streamed in chunks of 64 output
 // channels (chunk 0 already requested into W0 by the caller; double-buffered with the h image's LDS), the bf16 result chunk staged
 // through the wave's LDS rows so that whole 128-B row pieces are stored.
-template <int C>
+template <int C, int RT = 2>
 __device__ __forceinline__ void linear_chunks(const bf16_t* __restrict__ w, const float* __restrict__ bias, int N, bf16_t* __restrict__ out,
-                                              long ldo, long row0, long M, const bf16x8 (&hf)[C / 32][2], char* Hs, char* Us, char* W0,
+                                              long ldo, long row0, long M, const bf16x8 (&hf)[C / 32][RT], char* Hs, char* Us, char* W0,
                                               int wave, int lane, int lrow, int lq) {
     using K = MlpCfg<C>;
     const int nch = N / 64;
@@ -147,10 +151,13 @@ __device__ __forceinline__ void linear_chunks(const bf16_t* __restrict__ w, cons
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char* Wu = (ch & 1) ? Hs : W0;
-        if (ch + 1 < nch) stage_wup<C>(w, (ch + 1) * 64, (ch & 1) ? W0 : Hs, wave, lane);
-        f32x4 uacc[4][2];
+        if (ch + 1 < nch) stage_wup<C, 8 / RT>(w, (ch + 1) * 64, (ch & 1) ? W0 : Hs, wave, lane);
+        f32x4 uacc[4][RT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) uacc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < C / 32; ++ks) {
             const int c = ks * 4 + lq;
@@ -163,24 +170,24 @@ __device__ __forceinline__ void linear_chunks(const bf16_t* __restrict__ w, cons
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + ch * 64 + t * 16 + lq * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const f32x4 v = uacc[t][rt];
                 const bf16x4 pk = {(bf16_t)(v[0] + b4[0]), (bf16_t)(v[1] + b4[1]), (bf16_t)(v[2] + b4[2]), (bf16_t)(v[3] + b4[3])};
-                const int ur = wave * 32 + rt * 16 + lrow;
+                const int ur = wave * (16 * RT) + rt * 16 + lrow;
                 *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {                               // 8 rows x 128 B per pass, 16 B per lane
+        for (int it = 0; it < 2 * RT; ++it) {                          // 8 rows x 128 B per pass, 16 B per lane
             const int r = it * 8 + (lane >> 3), cidx = lane & 7;
-            const int ur = wave * 32 + r;
+            const int ur = wave * (16 * RT) + r;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((cidx ^ swz<8>(ur)) << 4));
             if (row0 + r < M) *reinterpret_cast<bf16x8*>(out + (row0 + r) * ldo + ch * 64 + cidx * 8) = v;
         }
@@ -188,8 +195,12 @@ __device__ __forceinline__ void linear_chunks(const bf16_t* __restrict__ w, cons
     }
 }
 
-template <int C, bool GATED>
-__global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
+// RT = 2: 4 waves x 32 rows (two waves per SIMD with two workgroups per CU).  RT = 1: 8 waves x 16 rows — half the accumulator /
+// fragment registers per wave, FOUR waves per SIMD: twice as many independent MFMA -> GELU -> MFMA chains to interleave, for twice the
+// LDS weight reads per row (not the limiter).  Same arithmetic per row: results are bit-identical.
+template <int C, bool GATED, int RT = 2>
+__global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel(const MlpArgs a) {
+    constexpr int NW = 8 / RT;
     using K = MlpCfg<C>;
     extern __shared__ __attribute__((aligned(16))) char mlp_smem[];
     // [ weight set 1 = h image during the LayerNorm | U | weight set 0 ]
@@ -199,24 +210,24 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
     static_assert(K::H_BYTES >= K::WUP_BYTES + K::WDN_BYTES, "the h image must be able to hold one weight chunk");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long row0 = (long)blockIdx.x * 128 + wave * 32;              // this wave's 32 rows
+    const long row0 = (long)blockIdx.x * 128 + wave * (16 * RT);              // this wave's 32 rows
     const int lrow = lane & 15, lq = lane >> 4;
 
-    stage_wup<C>(a.w_up, 0, W0, wave, lane);                           // chunk 0 weights fly under the LayerNorm
-    stage_wdn<C>(a.w_dn, 0, W0 + K::WUP_BYTES, wave, lane);
+    stage_wup<C, NW>(a.w_up, 0, W0, wave, lane);                           // chunk 0 weights fly under the LayerNorm
+    stage_wdn<C, NW>(a.w_dn, 0, W0 + K::WUP_BYTES, wave, lane);
 
     // ---- 1. LayerNorm -> operand fragments of the wave's rows (kept in VGPRs; the image's LDS becomes weight set 1).
     //         Without a gate the x values just read initialise the output accumulators (x + b_dn): x is never read again.
-    f32x4 oacc[C / 16][2];
-    bf16x8 hf[C / 32][2];
+    f32x4 oacc[C / 16][RT];
+    bf16x8 hf[C / 32][RT];
     {
         const LnSrc src{a.x, a.ldx, a.M, a.ln_w, a.ln_b, a.shift, a.scale, a.mod_sample_stride, a.rows_per_sample};
-        ln_rows_to_frags<C>(src, row0, Hs, wave, lrow, lq, oacc, hf);
+        ln_rows_to_frags<C, true, RT>(src, row0, Hs, wave, lrow, lq, oacc, hf);
 #pragma unroll
         for (int n = 0; n < C / 16; ++n) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + n * 16 + lq * 4);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) oacc[n][rt][j] = GATED ? 0.f : oacc[n][rt][j] + b4[j];
         }
@@ -236,12 +247,15 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
         char* Wd = Wu + K::WUP_BYTES;
         if (ch + 1 < K::NCH) {
             char* Wn = (ch & 1) ? W0 : Hs;
-            stage_wup<C>(a.w_up, (ch + 1) * K::HCH, Wn, wave, lane);
-            stage_wdn<C>(a.w_dn, (ch + 1) * K::HCH, Wn + K::WUP_BYTES, wave, lane);
+            stage_wup<C, NW>(a.w_up, (ch + 1) * K::HCH, Wn, wave, lane);
+            stage_wdn<C, NW>(a.w_dn, (ch + 1) * K::HCH, Wn + K::WUP_BYTES, wave, lane);
         }
-        f32x4 uacc[4][2];
+        f32x4 uacc[4][RT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { uacc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; uacc[t][1] = uacc[t][0]; }
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) uacc[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < C / 32; ++ks) {
             const int c = ks * 4 + lq;
@@ -254,14 +268,14 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt) uacc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], hf[ks][rt], uacc[t][rt], 0, 0, 0);
         }
         // bias + exact-erf GELU -> bf16 -> wave-private rows of U   (lane: hidden t*16 + lq*4 + i, row rt*16 + lrow)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_up + ch * K::HCH + t * 16 + lq * 4);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const f32x4 v = uacc[t][rt];
 #ifdef MLP_DBG_NOGELU
                 const f32x2 g0 = {v[0] + b4[0], v[1] + b4[1]}, g1 = {v[2] + b4[2], v[3] + b4[3]};
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
                 const f32x2 g1 = gelu_erf_fast2((f32x2){v[2] + b4[2], v[3] + b4[3]});
 #endif
                 const bf16x4 pk = {(bf16_t)g0[0], (bf16_t)g0[1], (bf16_t)g1[0], (bf16_t)g1[1]};
-                const int ur = wave * 32 + rt * 16 + lrow;
+                const int ur = wave * (16 * RT) + rt * 16 + lrow;
                 *reinterpret_cast<bf16x4*>(Us + ur * 128 + (((t * 2 + (lq >> 1)) ^ swz<8>(ur)) << 4) + (lq & 1) * 8) = pk;
             }
         }
@@ -278,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + lq;
-            bf16x8 uf[2];
+            bf16x8 uf[RT];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int ur = wave * 32 + rt * 16 + lrow;
+            for (int rt = 0; rt < RT; ++rt) {
+                const int ur = wave * (16 * RT) + rt * 16 + lrow;
                 uf[rt] = *reinterpret_cast<const bf16x8*>(Us + ur * 128 + ((c ^ swz<8>(ur)) << 4));
             }
 #pragma unroll
@@ -289,14 +303,14 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
                 const int wr = n * 16 + lrow;
                 const bf16x8 df = *reinterpret_cast<const bf16x8*>(Wd + wr * 128 + ((c ^ swz<8>(wr)) << 4));
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) oacc[n][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, uf[rt], oacc[n][rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt) oacc[n][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, uf[rt], oacc[n][rt], 0, 0, 0);
             }
         }
     }
 
     // ---- 3. store: lane holds channels n*16 + lq*4 .. +3 of row rt*16 + lrow ---------------------------------------
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const long grow = row0 + rt * 16 + lrow;
         if (grow >= a.M) continue;
         float* xr = a.x + grow * a.ldx;
@@ -332,10 +346,10 @@ __global__ __launch_bounds__(256, 2) void ln_mlp_resid_kernel(const MlpArgs a) {
     //         block that follows): its LN(x) . W^T is computed from the accumulators, so that block never reads x for it ----------
     if (a.next.w) {
         __syncthreads();                                               // every wave is done with both weight sets and its U rows
-        stage_wup<C>(a.next.w, 0, W0, wave, lane);
+        stage_wup<C, NW>(a.next.w, 0, W0, wave, lane);
         const LnSrc src{nullptr, 0, a.M, a.next.ln_w, a.next.ln_b, a.next.shift, a.next.scale, a.next.mod_sample_stride, a.next.rows_per_sample};
-        ln_rows_to_frags<C, false>(src, row0, Hs, wave, lrow, lq, oacc, hf);
-        linear_chunks<C>(a.next.w, a.next.bias, a.next.N, a.next.out, a.next.ldo, row0, a.M, hf, Hs, Us, W0, wave, lane, lrow, lq);
+        ln_rows_to_frags<C, false, RT>(src, row0, Hs, wave, lrow, lq, oacc, hf);
+        linear_chunks<C, RT>(a.next.w, a.next.bias, a.next.N, a.next.out, a.next.ldo, row0, a.M, hf, Hs, Us, W0, wave, lane, lrow, lq);
     }
 }
 
@@ -374,9 +388,15 @@ int launch_ln_linear(const LnLinArgs* a, hipStream_t st) {
 
 template <int C, bool GATED>
 int launch_mlp(const MlpArgs* a, hipStream_t st) {
-    LDT_ENSURE_LDS((&ln_mlp_resid_kernel<C, GATED>), MlpCfg<C>::LDS, "ln_mlp");
     const long blocks = (a->M + 127) / 128;
-    hipLaunchKernelGGL((ln_mlp_resid_kernel<C, GATED>), dim3((unsigned)blocks), dim3(256), MlpCfg<C>::LDS, st, *a);
+    static const int rt_env = getenv("LDT_MLP_RT") ? atoi(getenv("LDT_MLP_RT")) : 0;          // tools/dbg: 1 / 2 force
+    if ((rt_env ? rt_env : LDT_MLP_RT_DEFAULT) == 1) {
+        LDT_ENSURE_LDS((&ln_mlp_resid_kernel<C, GATED, 1>), MlpCfg<C>::LDS, "ln_mlp");
+        hipLaunchKernelGGL((ln_mlp_resid_kernel<C, GATED, 1>), dim3((unsigned)blocks), dim3(512), MlpCfg<C>::LDS, st, *a);
+        return ldt_check_launch("ln_mlp_resid");
+    }
+    LDT_ENSURE_LDS((&ln_mlp_resid_kernel<C, GATED, 2>), MlpCfg<C>::LDS, "ln_mlp");
+    hipLaunchKernelGGL((ln_mlp_resid_kernel<C, GATED, 2>), dim3((unsigned)blocks), dim3(256), MlpCfg<C>::LDS, st, *a);
     return ldt_check_launch("ln_mlp_resid");
 }
 
