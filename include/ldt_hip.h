@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 15
+#define LDT_ABI_VERSION 16
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -69,15 +69,19 @@ int ldt_gemm_bf16(int32_t epilogue, const uint16_t* X, int64_t ldx, const uint16
  * ldt_gemm_lnfold (consumer):  out bf16 = epi(r * (Xs W^T) - r * mu * fold_S + fold_C), epilogue LDT_EPI_BF16 or
  *     LDT_EPI_GELU_BF16; the row statistics are those of the K = stats_parts*256 input channels (K <= 1024).
  * ln_scale / fold_S / fold_C / gate are addressed base + (*step_ptr) * their step stride (step_ptr NULL = 0).
- * M, N multiples of 256, K >= 256; the host builds S and C in fp32 from the SAME bf16 W the GEMM reads. */
+ * stats_parts selects the statistics granule and with it the kernel family: N/256 (producer) | K/256 (consumer) partials per row — the
+ *     256-tile kernels: M, N multiples of 256, K >= 256, K <= 1024 for the consumer; N/32 | K/32 — the small-batch kernels (batches
+ *     of 1-2 k rows, where every GEMM of a Score block runs 64-wide tiles): M a multiple of 128, N of 64.  A producer and the consumer
+ *     of its statistics must use the same granule.  The host builds S and C in fp32 from the SAME bf16 W the GEMM reads. */
 int ldt_gemm_resid_lnstats(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, const float* bias,
                            float* out, int64_t ldo, const float* gate, int64_t gate_sample_stride,
                            int32_t rows_per_sample, const float* ln_scale, uint16_t* xs, int64_t ldxs,
                            float* stats_out, const int32_t* step_ptr, int64_t gate_step_stride,
-                           int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, void* stream);
+                           int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, int32_t stats_parts, void* stream);
 int ldt_gemm_lnfold(int32_t epilogue, const uint16_t* Xs, int64_t ldx, const uint16_t* W, int64_t ldw,
                     const float* stats_in, const float* fold_S, const float* fold_C, uint16_t* out, int64_t ldo,
-                    const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, void* stream);
+                    const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, int32_t stats_parts,
+                    void* stream);
 
 /* ---- LayerNorm(eps 1e-6) [+affine] [+AdaLN modulate] -> bf16 -----------------------------------------
  * y = LN(x)[*w+b] * (1 + scale[s]) + shift[s].  tools/utils.py:127-133 + model/layers.py:136-137,218-219.

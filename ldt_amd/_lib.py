@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -49,8 +49,8 @@ SIGNATURES = {
     "ldt_gemm_bf16": [_i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64,
                       _i32, _i32, _i32, _vp],
     "ldt_gemm_resid_lnstats": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
-                               _i32, _i32, _i32, _vp],
-    "ldt_gemm_lnfold": [_i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
+                               _i32, _i32, _i32, _i32, _vp],
+    "ldt_gemm_lnfold": [_i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "ldt_gemm_bf16_splitk": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "ldt_layernorm_modulate_resid": [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
     "ldt_layernorm_modulate": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],

@@ -62,19 +62,23 @@ extern "C" int ldt_gemm_resid_lnstats(const uint16_t* X, int64_t ldx, const uint
                                       float* out, int64_t ldo, const float* gate, int64_t gate_sample_stride,
                                       int32_t rows_per_sample, const float* ln_scale, uint16_t* xs, int64_t ldxs,
                                       float* stats_out, const int32_t* step_ptr, int64_t gate_step_stride,
-                                      int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, void* stream) {
+                                      int64_t ln_step_stride, int32_t M, int32_t N, int32_t K, int32_t stats_parts, void* stream) {
     LDT_REQUIRE(X && W && out && xs && ln_scale && stats_out, LDT_EARG, "gemm_resid_lnstats: null pointer");
+    LDT_REQUIRE(stats_parts == N / 256 || stats_parts == N / 32, LDT_EARG, "gemm_resid_lnstats: stats_parts=%d is neither N/256 nor N/32 (N=%d)", stats_parts, N);
     GemmArgs a{BF(X), ldx, BF(W), ldw, bias, out, ldo, out, ldo, nullptr, 0, gate, gate_sample_stride, rows_per_sample, step_ptr,
                gate_step_stride, M, N, K, BFM(xs), ldxs, ln_scale, ln_step_stride, stats_out};
+    a.stats_parts = stats_parts;
     return ldt_gemm_lnfold_launch(EPI_RESID_F32, &a, ST(stream));
 }
 
 extern "C" int ldt_gemm_lnfold(int32_t epilogue, const uint16_t* Xs, int64_t ldx, const uint16_t* W, int64_t ldw,
                                const float* stats_in, const float* fold_S, const float* fold_C, uint16_t* out, int64_t ldo,
-                               const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, void* stream) {
+                               const int32_t* step_ptr, int64_t fold_step_stride, int32_t M, int32_t N, int32_t K, int32_t stats_parts,
+                               void* stream) {
     LDT_REQUIRE(Xs && W && out && stats_in && fold_S && fold_C, LDT_EARG, "gemm_lnfold: null pointer");
+    LDT_REQUIRE(stats_parts == K / 256 || stats_parts == K / 32, LDT_EARG, "gemm_lnfold: stats_parts=%d is neither K/256 nor K/32 (K=%d)", stats_parts, K);
     GemmArgs a{BF(Xs), ldx, BF(W), ldw, nullptr, out, ldo, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, N, K,
-               nullptr, 0, nullptr, 0, nullptr, stats_in, K / 256, fold_S, fold_C, fold_step_stride};
+               nullptr, 0, nullptr, 0, nullptr, stats_in, stats_parts, fold_S, fold_C, fold_step_stride};
     return ldt_gemm_lnfold_launch(epilogue, &a, ST(stream));
 }
 
@@ -294,8 +298,11 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     // LN folding (gemm_bf16.hip): with batch-shared modulation (unconditional sampling) the LayerNorm + modulate between a
     // residual GEMM and the next projection is folded into the two GEMMs' epilogues; the host supplies the per-step
     // S / C tables (plan->fold) when that pays (whole 256x256 tiles that fill the chip: Score.can_fold).
-    bool fold = p->fold && p->stats && sstr == 0 && M % 256 == 0 && D % 256 == 0 && D <= 1024 && F % 256 == 0;
+    // Small batches whose GEMMs all run the v1 kernels fold through those (statistics per 32 columns), the rest through the 256-tile kernel.
+    const bool fold_v1 = ldt_gemm_lnfold_v1_route(M, D, F, p->gemm_wgs);
+    bool fold = p->fold && p->stats && sstr == 0 && (M % 256 == 0 || fold_v1) && D % 256 == 0 && D <= 1024 && F % 256 == 0;
     for (int l = 0; l < p->blocks && fold; ++l) fold = !p->kv_cond[l];
+    const int sparts = fold_v1 ? D / 32 : D / 256;              // row-statistics partials per row in plan->stats ([sparts][M][2])
     const long fstep = p->fold_step_stride, fblk = 6L * D + 2L * F;   // per block: S_qkv[3D] | C_qkv[3D] | S_up[F] | C_up[F]
     // Split-K for the residual GEMMs of a small batch (include/ldt_hip.h, ldt_score_plan.splitk_ws) — OPT-IN (LDT_SPLITK=1, or =n to
     // force n splits).  With N = hidden = 1024 a 1-2k-row batch has 32-128 output tiles of 128^2 for 256 CUs, and smaller tiles stream
@@ -329,7 +336,7 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         const float* fl = fold ? p->fold + (long)l * fblk : nullptr;
         if (fold && l > 0) {                                    // Hb = x (1 + scale_msa) and the row statistics came from block l-1's mlp.out
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, nullptr, p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, 3 * D, D,
-                        nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl, fl + 3L * D, fstep};
+                        nullptr, 0, nullptr, 0, nullptr, p->stats, sparts, fl, fl + 3L * D, fstep};
             gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
@@ -357,17 +364,17 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             // fc_o + gate + residual, also emitting Hb = x (1 + scale_mlp) and the row statistics; mlp.fc consumes them
             GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D,
                         BFM(p->Hb), D, m + 4 * D, tstr, p->stats};
-            go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
-            if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, D / 256, M, D, p->fold_monitor, s));
+            go.max_wgs = p->gemm_wgs; go.stats_parts = sparts; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &go, s));
+            if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, sparts, M, D, p->fold_monitor, s));
             GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, nullptr, p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, F, D,
-                        nullptr, 0, nullptr, 0, nullptr, p->stats, D / 256, fl + 6L * D, fl + 6L * D + F, fstep};
+                        nullptr, 0, nullptr, 0, nullptr, p->stats, sparts, fl + 6L * D, fl + 6L * D + F, fstep};
             gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_lnfold_launch(LDT_EPI_GELU_BF16, &gu, s));
             GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F,
                         BFM(p->Hb), D, m + 6 * D + D, tstr, p->stats};      // next block's scale_msa
-            gd.max_wgs = p->gemm_wgs;
+            gd.max_wgs = p->gemm_wgs; gd.stats_parts = sparts;
             if (l + 1 < p->blocks) {
                 LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_lnfold_launch(LDT_EPI_RESID_F32, &gd, s));
-                if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, D / 256, M, D, p->fold_monitor, s));
+                if (p->fold_monitor) TRY(ldt_fold_monitor_launch(p->stats, sparts, M, D, p->fold_monitor, s));
             }
             else LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));    // FinalLayer's LN runs as a kernel
             continue;

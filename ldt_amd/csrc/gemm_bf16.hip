@@ -28,6 +28,8 @@
 
 #define BK 64
 
+enum { FOLD_NONE = 0, FOLD_PRODUCER = 1, FOLD_CONSUMER = 2 };   // LN folding (described at the 256-tile kernel below)
+
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
                                            int k0, char* lds_tile, int wave, int lane) {
@@ -55,7 +57,13 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
 // NW = 8 (512 threads, waves 4 x 2 over the tile): the mid-size form — a 256 x 128 tile with a 3-stage ring is ONE workgroup per CU
 // whose operand stream carries 85 flop per byte (128 x 64 tiles: 43), for the batches whose GEMMs are bound by the per-CU
 // L2 -> LDS rate (M = 1-4 k rows; DESIGN.md §4 "small-batch regime").
-template <int EPI, int TBM, int TBN, int NST = 2, int NW = 4>
+// FOLD (small batches: every GEMM of a Score block on this kernel, Score.can_fold / ldt_gemm_lnfold_v1_route): the LN-folding
+// forms of the 256-tile kernel below with the row statistics kept per 32 output columns — a wave's half of a 64-wide tile —
+//   FOLD_PRODUCER (EPI_RESID_F32, TBN = 64, M % TBM == 0): also stores xs = bf16(x_new (1 + ln_scale)) and the wave's per-row
+//     (sum, sum of squares) over its 32 columns -> stats_out[n / 32][M][2] (cross-lane adds in a fixed order, no atomics);
+//   FOLD_CONSUMER (EPI_BF16 / EPI_GELU_BF16): X = xs; the tile's rows' K/32 partials are summed in part order under the first
+//     operand round trip (thread r < TBM: row r) into (rstd, -mean rstd) in LDS; the epilogue is y = rstd acc + (-mean rstd S + C).
+template <int EPI, int TBM, int TBN, int NST = 2, int NW = 4, int FOLD = FOLD_NONE>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a) {
     constexpr int BM = TBM, BN = TBN;
     constexpr int XB = TBM * BK * 2, WB = TBN * BK * 2;               // operand tile bytes per stage
@@ -63,6 +71,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
     constexpr int MT = TBM / (16 * WGM), NT = TBN / 32;               // 16x16 accumulator tiles per wave (m, n)
     constexpr int OPS = (TBM + TBN) / (8 * NW);                       // LDS-DMA instructions per wave and stage
     __shared__ __attribute__((aligned(16))) char smem[NST * (XB + WB)];  // [stage][X|W]
+    __shared__ float fold_rs[FOLD == FOLD_CONSUMER ? TBM * 2 : 2];       // (rstd, -mean rstd) of the tile's rows
+    __shared__ __attribute__((aligned(16))) float fold_sc[FOLD == FOLD_CONSUMER ? 2 * TBN : 4];   // this tile's slices of fold_S | fold_C
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,7 +114,49 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
             stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
             ++ahead;
         }
-    if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+    if (FOLD == FOLD_CONSUMER) {
+        // row statistics of this tile's rows, in flight together with the first operand stages (VMEM retires in order: the wait
+        // the compiler places before the arithmetic below also covers those stages — one round trip in all)
+        // 256 / TBM threads per row, each takes a contiguous run of the <= 32 partials: all of a thread's loads are issued before the
+        // first add (an in-order loop would be one memory round trip per partial), then run, then threads, are added in index order
+        constexpr int TPR = NW * 64 / TBM, PPT = 32 / TPR;
+        {
+            int row = m0 + tid / TPR;
+            row = row < a.M ? row : a.M - 1;
+            const int p0 = (tid % TPR) * PPT;
+            const float* sp = a.stats_in + (long)row * 2;
+            f32x2 t[PPT];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) t[i] = (p0 + i < a.stats_parts) ? *reinterpret_cast<const f32x2*>(sp + (long)(p0 + i) * a.M * 2) : (f32x2){0.f, 0.f};
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) { s1 += t[i][0]; s2 += t[i][1]; }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) {                       // partner threads are adjacent lanes: lower run + upper run
+                const float o1 = __shfl_xor(s1, o, 64), o2 = __shfl_xor(s2, o, 64);
+                s1 = (tid & o) ? o1 + s1 : s1 + o1;
+                s2 = (tid & o) ? o2 + s2 : s2 + o2;
+            }
+            // the tile's S | C slices are step-indexed, hence cold in every cache at every step: fetched here, inside the prologue's one
+            // round trip, so that the epilogue opens on LDS reads (the 256-tile kernel rides its mid-loop DMA slot for the same reason)
+            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
+            const int scn = (tid & (TBN / 4 - 1)) * 4;
+            const bool sc_lane = tid < 2 * (TBN / 4) && n0 + scn < a.N;
+            if (sc_lane) {
+                const long fst = a.step_ptr ? (long)(*a.step_ptr) * a.fold_step_stride : 0L;
+                sc4 = *reinterpret_cast<const f32x4*>((tid < TBN / 4 ? a.fold_S : a.fold_C) + fst + n0 + scn);
+            }
+            if (tid < 2 * (TBN / 4)) *reinterpret_cast<f32x4*>(&fold_sc[(tid < TBN / 4 ? 0 : TBN) + scn]) = sc4;
+            if (tid % TPR == 0) {
+                const float invk = 1.0f / (float)a.K;
+                const float mean = s1 * invk;
+                const float var = fmaxf(s2 * invk - mean * mean, 0.f);
+                const float r = rsqrtf(var + 1e-6f);
+                fold_rs[(tid / TPR) * 2] = r; fold_rs[(tid / TPR) * 2 + 1] = -mean * r;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
     else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -153,12 +205,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
     // ---- epilogue: lane holds D[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)], r = 0..3 ----
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+    const long fstep = (FOLD != FOLD_NONE && a.step_ptr) ? (long)(*a.step_ptr) : 0L;
+    const float* lsc = FOLD == FOLD_PRODUCER ? a.ln_scale + fstep * a.ln_step_stride : nullptr;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         const int m = m0 + wm * (TBM / WGM) + mi * 16 + lrow;
         if (m >= a.M) continue;
         const float* grow = nullptr;
         if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
+        float rr = 1.f, nm = 0.f, s1 = 0.f, s2 = 0.f;
+        if (FOLD == FOLD_CONSUMER) { rr = fold_rs[(m - m0) * 2]; nm = fold_rs[(m - m0) * 2 + 1]; }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int n = n0 + wn * (TBN / 2) + ni * 16 + lchk * 4;
@@ -170,8 +226,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                 if (full) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n); b[0] = t[0]; b[1] = t[1]; b[2] = t[2]; b[3] = t[3]; }
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) b[r] = a.bias[n + r];
             }
+            if (FOLD == FOLD_CONSUMER) {                            // y = rstd acc + (-mean rstd S + C): the bias is inside C (N % 64 == 0 here)
+                const f32x4 S4 = *reinterpret_cast<const f32x4*>(&fold_sc[n - n0]), C4 = *reinterpret_cast<const f32x4*>(&fold_sc[TBN + n - n0]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += b[r];
+                for (int r = 0; r < 4; ++r) v[r] = rr * v[r] + (nm * S4[r] + C4[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
             if (EPI == EPI_F32) {
                 float* o = reinterpret_cast<float*>(a.out) + (a.splits > 1 ? (long)blockIdx.y * a.split_stride : 0L) + (long)m * a.ldo + n;
                 if (full) *reinterpret_cast<f32x4*>(o) = v;
@@ -189,6 +251,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                         for (int r = 0; r < 4; ++r) x[r] = x[r] + v[r];
                     }
                     *reinterpret_cast<f32x4*>(o) = x;
+                    if (FOLD == FOLD_PRODUCER) {
+                        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(lsc + n);
+                        const bf16x4 pk = {(bf16_t)(x[0] * (1.f + sc4[0])), (bf16_t)(x[1] * (1.f + sc4[1])), (bf16_t)(x[2] * (1.f + sc4[2])),
+                                           (bf16_t)(x[3] * (1.f + sc4[3]))};
+                        *reinterpret_cast<bf16x4*>(a.xs + (long)m * a.ldxs + n) = pk;
+                        s1 += (x[0] + x[1]) + (x[2] + x[3]);
+                        s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                    }
                 } else {
                     for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = rs[r] + (grow ? grow[n + r] : 1.f) * v[r];
                 }
@@ -214,6 +284,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                     *reinterpret_cast<bf16x4*>(o) = pk;
                 } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
             }
+        }
+        if (FOLD == FOLD_PRODUCER) {                                // the four lanes of a row (lchk = 0..3), fixed order; whole tiles only
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lchk == 0)
+                *reinterpret_cast<f32x2*>(a.stats_out + ((long)((n0 + wn * (TBN / 2)) / (TBN / 2)) * a.M + m) * 2) = (f32x2){s1, s2};
         }
     }
 }
@@ -336,7 +412,6 @@ __device__ __forceinline__ float row16_sum(float v) {
 //   (four half-wave pieces) so that the epilogue opens on LDS reads instead of an HBM round trip.  For the same reason
 //   the residual epilogue's step-indexed gate / ln_scale vectors of a workgroup's first tile are loaded before the
 //   main loop and kept in 8 VGPRs.
-enum { FOLD_NONE = 0, FOLD_PRODUCER = 1, FOLD_CONSUMER = 2 };
 #define V2_STATS_OFF 2304            /* bf16 staging uses 16 rows x 144 B of each wave's 4 KiB */
 #define V2_SC_OFF (V2_STATS_OFF + 1024)   /* 512 B: a 128-column slice of fold_S (waves 0, 1) or fold_C (waves 2, 3) */
 
@@ -1115,9 +1190,43 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
 }
 
 // LN-folding launches: always the 256-tile kernel, interior + aligned tiles only (checked here, assumed by the kernel).
+// All four GEMMs of a Score block (N = D, 3D, F) fall to the v1 kernels under ldt_gemm_launch's 5/8 rule: the batches whose LN folding
+// runs in the v1 FOLD forms (statistics per 32 columns: stats[D / 32][M][2]).  M % 128 == 0: whole tiles (the producer's row sums).
+static int gemm_variant_env() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LDT_GEMM_FORCE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs) {
+    const int lim = (max_wgs > 0 && max_wgs < LDT_NUM_CUS) ? max_wgs : LDT_NUM_CUS;
+    auto small = [&](int N) { return (long)((M + 255) / 256) * ((N + 255) / 256) * 8 < (long)lim * 5; };
+    return gemm_variant_env() == 0 && M % 128 == 0 && D % 64 == 0 && F % 64 == 0 && small(D) && small(3 * D) && small(F);
+}
+
+// v1 FOLD forms: TBN = 64 tiles (the statistics granule is a wave's 32-column half), 128 x 64 when that still gives every CU two tiles
+template <int EPI, int FOLD>
+static int launch_v1_fold(const GemmArgs* a, hipStream_t stream) {
+    auto ntiles = [&](int bm, int bn) { return (long)(a->M / bm) * (a->N / bn); };
+    GemmArgs b = *a;
+    const bool big = FOLD == FOLD_CONSUMER && a->N % 128 == 0 && ntiles(128, 128) >= 2 * LDT_NUM_CUS;   // (consumers only: the producer's granule is a 32-column half tile)
+    const bool wide = ntiles(128, 64) >= 2 * LDT_NUM_CUS;
+    const long tm = a->M / (wide || big ? 128 : 64), tn = a->N / (big ? 128 : 64);
+    b.col_major = tn >= 3 * tm ? 1 : 0;
+    if (big) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 128, 128, 2, 4, FOLD == FOLD_CONSUMER ? FOLD_CONSUMER : FOLD_NONE>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, stream, b);
+    else if (wide) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 128, 64, 2, 4, FOLD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 64, 64, 3, 4, FOLD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, stream, b);
+    return ldt_check_launch("gemm_bf16_nt(fold)");
+}
+
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
-    LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K >= 256 && a->M % 256 == 0 && a->N % 256 == 0 && a->K % BK == 0, LDT_ESHAPE,
-                "gemm_lnfold: M=%d N=%d must be multiples of 256 and K=%d >= 256, K %% 64 == 0", a->M, a->N, a->K);
+    // route: stats_parts says which statistics layout the caller's buffers use — K / 256 (N / 256 for the producer) parts: the 256-tile
+    // kernel; K / 32 (N / 32): the v1 kernel (ldt_gemm_lnfold_v1_route)
+    const int width = epi == EPI_RESID_F32 ? a->N : a->K;
+    const bool v1 = a->stats_parts > 0 && a->stats_parts * 32 == width && a->stats_parts * 256 != width;
+    if (v1) LDT_REQUIRE(a->M > 0 && a->M % 128 == 0 && a->N % 64 == 0 && a->K >= 128 && a->K % BK == 0, LDT_ESHAPE,
+                        "gemm_lnfold (v1 route): M=%d must be a multiple of 128, N=%d of 64, K=%d >= 128, K %% 64 == 0", a->M, a->N, a->K);
+    else LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K >= 256 && a->M % 256 == 0 && a->N % 256 == 0 && a->K % BK == 0, LDT_ESHAPE,
+                     "gemm_lnfold: M=%d N=%d must be multiples of 256 and K=%d >= 256, K %% 64 == 0", a->M, a->N, a->K);
     LDT_REQUIRE(a->ldx % 8 == 0 && a->ldw % 8 == 0 && a->ldx >= a->K && a->ldw >= a->K && a->ldo % 8 == 0 && ldt_aligned16(a->X) &&
                 ldt_aligned16(a->W) && ldt_aligned16(a->out), LDT_EALIGN, "gemm_lnfold: operands must be 16-byte aligned (ldx=%ld ldw=%ld ldo=%ld)",
                 a->ldx, a->ldw, a->ldo);
@@ -1129,21 +1238,23 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
         LDT_REQUIRE(a->xs && a->ln_scale && a->stats_out && a->ldxs % 4 == 0 && a->ldxs >= a->N && ldt_aligned16(a->xs) &&
                     ldt_aligned16(a->ln_scale) && a->ln_step_stride % 4 == 0 && ldt_aligned16(a->stats_out), LDT_EARG,
                     "gemm_lnfold: producer needs xs / ln_scale / stats_out (16-byte aligned)");
+        if (v1) return launch_v1_fold<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
         return launch_256<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
     }
     LDT_REQUIRE(epi == EPI_BF16 || epi == EPI_GELU_BF16, LDT_EARG, "gemm_lnfold: epilogue %d has no folded form", epi);
-    LDT_REQUIRE(a->stats_in && a->fold_S && a->fold_C && a->stats_parts >= 1 && a->stats_parts <= 4 && a->stats_parts * 256 == a->K &&
-                ldt_aligned16(a->stats_in) && ldt_aligned16(a->fold_S) && ldt_aligned16(a->fold_C) && a->fold_step_stride % 4 == 0, LDT_EARG,
-                "gemm_lnfold: consumer needs stats_in[K/256 <= 4][M][2], fold_S, fold_C (16-byte aligned); K=%d parts=%d", a->K, a->stats_parts);
+    LDT_REQUIRE(a->stats_in && a->fold_S && a->fold_C && ldt_aligned16(a->stats_in) && ldt_aligned16(a->fold_S) && ldt_aligned16(a->fold_C) &&
+                a->fold_step_stride % 4 == 0, LDT_EARG, "gemm_lnfold: consumer needs stats_in, fold_S, fold_C (16-byte aligned)");
+    if (v1) {
+        LDT_REQUIRE(a->stats_parts <= 32, LDT_ESHAPE, "gemm_lnfold (v1 route): K=%d > 1024 input channels", a->K);
+        return epi == EPI_BF16 ? launch_v1_fold<EPI_BF16, FOLD_CONSUMER>(a, stream) : launch_v1_fold<EPI_GELU_BF16, FOLD_CONSUMER>(a, stream);
+    }
+    LDT_REQUIRE(a->stats_parts >= 1 && a->stats_parts <= 4 && a->stats_parts * 256 == a->K, LDT_EARG,
+                "gemm_lnfold: consumer needs stats_in[K/256 <= 4][M][2] (or [K/32][M][2] for the small-batch kernels); K=%d parts=%d", a->K, a->stats_parts);
     return epi == EPI_BF16 ? launch_256<EPI_BF16, FOLD_CONSUMER>(a, stream) : launch_256<EPI_GELU_BF16, FOLD_CONSUMER>(a, stream);
 }
 
 // LDT_GEMM_FORCE=128|256 pins the variant (A/B runs); default: see ldt_gemm_launch.
-static int gemm_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LDT_GEMM_FORCE"); v = e ? atoi(e) : 0; }
-    return v;
-}
+static int gemm_variant() { return gemm_variant_env(); }
 
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     LDT_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, LDT_ESHAPE, "gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);

@@ -76,6 +76,7 @@ struct SgemmArgs {
 };
 
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
+bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // every GEMM of a Score block on the v1 kernels: statistics per 32 columns
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);

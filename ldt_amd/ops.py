@@ -73,36 +73,37 @@ def gemm_bf16(x, w, bias=None, epilogue=EPI_BF16, out=None, resid=None, skip=Non
 
 
 def gemm_resid_lnstats(x, w, bias, out, ln_scale, gate=None, gate_sample_stride=0, rows_per_sample=0, step_ptr=None,
-                       gate_step_stride=0, ln_step_stride=0):
+                       gate_step_stride=0, ln_step_stride=0, granule=256):
     """LN-folding producer: out += gate * (x @ w^T + bias) in place (fp32), and returns
-    (xs bf16 [M,N] = out * (1 + ln_scale), stats fp32 [N/256, M, 2] = per-row (sum, sumsq) of out per 256-column tile)."""
+    (xs bf16 [M,N] = out * (1 + ln_scale), stats fp32 [N/granule, M, 2] = per-row (sum, sumsq) of out per `granule` columns:
+    256 = the 256-tile kernel, 32 = the small-batch kernel)."""
     _need(x, torch.bfloat16, "x"); _need(w, torch.bfloat16, "w"); _need(bias, torch.float32, "bias")
     _need(out, torch.float32, "out"); _need(ln_scale, torch.float32, "ln_scale")
     _rowmajor(x, "x"); _rowmajor(w, "w"); _rowmajor(out, "out")
     M, K = x.shape
     N = w.shape[0]
     xs = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    stats = torch.empty((N // 256, M, 2), dtype=torch.float32, device=x.device)
+    stats = torch.empty((N // granule, M, 2), dtype=torch.float32, device=x.device)
     check(lib().ldt_gemm_resid_lnstats(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), _p(gate),
                                        gate_sample_stride, rows_per_sample, _p(ln_scale), _p(xs), xs.stride(0), _p(stats),
-                                       _p(step_ptr), gate_step_stride, ln_step_stride, M, N, K, stream_ptr()),
+                                       _p(step_ptr), gate_step_stride, ln_step_stride, M, N, K, N // granule, stream_ptr()),
           "ldt_gemm_resid_lnstats")
     return xs, stats
 
 
 def gemm_lnfold(xs, w, stats, fold_s, fold_c, epilogue=EPI_BF16, step_ptr=None, fold_step_stride=0):
     """LN-folding consumer: bf16 [M,N] = epi(rstd * (xs @ w^T) - rstd * mean * fold_s + fold_c), (mean, rstd) per row
-    from `stats` [K/256, M, 2]."""
+    from `stats` [K/256, M, 2] (256-tile kernels) or [K/32, M, 2] (small-batch kernels), as its producer wrote them."""
     _need(xs, torch.bfloat16, "xs"); _need(w, torch.bfloat16, "w"); _need(stats, torch.float32, "stats")
     _need(fold_s, torch.float32, "fold_s"); _need(fold_c, torch.float32, "fold_c")
     _rowmajor(xs, "xs"); _rowmajor(w, "w")
     M, K = xs.shape
     N = w.shape[0]
-    if tuple(stats.shape) != (K // 256, M, 2) or not stats.is_contiguous():
-        raise ValueError("gemm_lnfold: stats must be contiguous [K/256, M, 2]")
+    if tuple(stats.shape) not in ((K // 256, M, 2), (K // 32, M, 2)) or not stats.is_contiguous():
+        raise ValueError("gemm_lnfold: stats must be contiguous [K/256, M, 2] or [K/32, M, 2]")
     out = torch.empty((M, N), dtype=torch.bfloat16, device=xs.device)
     check(lib().ldt_gemm_lnfold(epilogue, _p(xs), xs.stride(0), _p(w), w.stride(0), _p(stats), _p(fold_s), _p(fold_c), _p(out),
-                                out.stride(0), _p(step_ptr), fold_step_stride, M, N, K, stream_ptr()), "ldt_gemm_lnfold")
+                                out.stride(0), _p(step_ptr), fold_step_stride, M, N, K, stats.shape[0], stream_ptr()), "ldt_gemm_lnfold")
     return out
 
 

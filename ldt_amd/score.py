@@ -200,7 +200,7 @@ class Score(nn.Module):
                 "X": torch.empty((M, D), dtype=torch.float32, device=dev),
                 "Hb": torch.empty((M, D), **bf), "QKV": torch.empty((M, 3 * D), **bf),
                 "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
-                "stats": torch.empty((max(D // 256, 1), M, 2), dtype=torch.float32, device=dev),
+                "stats": torch.empty((max(D // 32, 1), M, 2), dtype=torch.float32, device=dev),   # [D/256] (256-tile kernels) or [D/32] (small-batch kernels) partials per row
             }
             if M <= self.SPLITK_MAX_ROWS and D % 256 == 0 and D <= 1024:          # small batch: split-K partials of the residual GEMMs
                 self._ws[k]["P"] = torch.empty((self.SPLITK_PARTS, M, D), dtype=torch.float32, device=dev)
@@ -273,14 +273,26 @@ class Score(nn.Module):
         """LN folding pays when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs' tiles fill at
         least 5/8 of the workgroups they may use (all 256 CUs, or a sub-batch stream's share `gemm_wgs`) — the same rule
         by which ldt_gemm_launch prefers the 256^2 kernel; at M = 8192 on the whole chip the 128^2 kernel + LayerNorm
-        launches measured 3 % faster.  LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
+        launches measured 3 % faster — or, for small batches (the shipped 32-token config: M = 2048), when EVERY GEMM of the
+        block runs the small-tile kernels, whose LN-folding forms keep the row statistics per 32 columns
+        (ldt_gemm_lnfold_v1_route in csrc/gemm_bf16.hip; this predicate mirrors it).
+        LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
+        F = self.Transformer[0].mlp.out.in_channels if not self.unet else 0
         if self._fold_disabled and mode != 2:
             return False
-        if mode == 0 or self.unet or D % 256 or D > 1024 or M % 256 or self.Transformer[0].mlp.out.in_channels % 256:
+        if mode == 0 or self.unet or D % 256 or D > 1024 or F % 256:
             return False
         lim = gemm_wgs if 0 < gemm_wgs < 256 else 256
+        t256 = lambda n: -(-M // 256) * -(-n // 256)
+        small = M % 128 == 0 and not int(os.environ.get("LDT_GEMM_FORCE", "0")) and all(t256(n) * 8 < lim * 5 for n in (D, 3 * D, F))
+        if small:
+            # measured neutral at the shipped 32-token config (B = 64: 3.04 vs 3.05 ms per SDE step; producers +2 us, consumers +2-5 us
+            # against two 5.5-us LayerNorm launches, tools/dbg/fold_small_ab.py): opt-in
+            return mode == 2 or bool(int(os.environ.get("LDT_LN_FOLD_SMALL", "0")))
+        if M % 256:
+            return False
         return mode == 2 or (M // 256) * (D // 256) * 8 >= lim * 5
 
     # The folded projections round x (1 + scale) to bf16 BEFORE the row mean is removed: their operand-rounding error is

@@ -69,9 +69,12 @@ def test_gemm_all_epilogues(M, N, K):
     assert rel_mse(rd.cpu(), resid.double() + ref) < 1e-9
 
 
-@pytest.mark.parametrize("M,D,N2,gelu", [(512, 1024, 768, False), (256, 512, 2048, True), (768, 256, 256, False),
-                                         (66560, 256, 256, True)])          # 260 tiles: persistent workgroups take a 2nd tile
-def test_gemm_lnfold_pair(M, D, N2, gelu):
+@pytest.mark.parametrize("M,D,N2,gelu,granule", [(512, 1024, 768, False, 256), (256, 512, 2048, True, 256), (768, 256, 256, False, 256),
+                                                 (66560, 256, 256, True, 256),     # 260 tiles: persistent workgroups take a 2nd tile
+                                                 # the small-batch kernels (statistics per 32 columns): 64x64 and 128x64 tile forms
+                                                 (2048, 1024, 3072, False, 32), (2048, 1024, 4096, True, 32), (1024, 1024, 1024, False, 32),
+                                                 (128, 256, 64, True, 32), (4096, 1024, 1024, False, 32), (384, 512, 192, False, 32)])
+def test_gemm_lnfold_pair(M, D, N2, gelu, granule):
     """LN folding (include/ldt_hip.h): residual GEMM that also emits xs = x(1+scale) + row statistics, then the
     projection that applies the LayerNorm algebraically in its epilogue — against LayerNorm -> modulate -> Linear in
     fp64 on the same bf16 weights.  The row mean is deliberately NOT small (|mean| ~ 0.5 std)."""
@@ -87,15 +90,16 @@ def test_gemm_lnfold_pair(M, D, N2, gelu):
     # ---- producer
     xd = dev(x0.clone())
     xs, stats = ops.gemm_resid_lnstats(dev(a, torch.bfloat16), dev(wo, torch.bfloat16), dev(bo), xd, dev(sc), gate=dev(gate),
-                                       gate_sample_stride=D, rows_per_sample=rps)
+                                       gate_sample_stride=D, rows_per_sample=rps, granule=granule)
     xref = x0.double() + gate.double().repeat_interleave(rps, 0) * (a.double() @ wo.double().T + bo.double())
     assert rel_mse(xd.cpu(), xref) < 1e-9
     assert rel_mse(xs.float().cpu(), xref * (1 + sc.double())) < 1e-5
     st = stats.cpu().double()
-    tiles = xd.cpu().double().view(M, D // 256, 256)
+    assert stats.shape == (D // granule, M, 2)
+    tiles = xd.cpu().double().view(M, D // granule, granule)
     assert rel_mse(st[..., 0], tiles.sum(-1).T) < 1e-10 and rel_mse(st[..., 1], (tiles ** 2).sum(-1).T) < 1e-10
     again = ops.gemm_resid_lnstats(dev(a, torch.bfloat16), dev(wo, torch.bfloat16), dev(bo), dev(x0.clone()), dev(sc), gate=dev(gate),
-                                   gate_sample_stride=D, rows_per_sample=rps)
+                                   gate_sample_stride=D, rows_per_sample=rps, granule=granule)
     assert torch.equal(again[0], xs) and torch.equal(again[1], stats)          # fixed summation order: reproducible
     # ---- consumer
     S = (w2.double() * (1 + sc.double())).sum(1).float(); C = (w2.double() @ sh.double() + b2.double()).float()
