@@ -1,7 +1,9 @@
-"""VP-SDE and the discrete reverse-SDE sampler (reference: diffusion/diffusion_continuous.py).
+"""The SDE families and the discrete reverse-SDE sampler (reference: diffusion/diffusion_continuous.py).
 
-`DiffusionVPSDE` keeps the reference constructor (`args` = cfg.sde Namespace) and the members the path
-uses: `f, g2, var, std, e2int_f, betas, alpha, alphas_cump, N, sample_discrete(...)` (:626-678, :133-338).
+`DiffusionBase` holds the samplers, written against the schedule (`f, g2, var, e2int_f`) a family supplies: `DiffusionVPSDE` (:626-678;
+also `betas, alpha, alphas_cump, N` for the ancestral / ddim / PNDM predictors), `DiffusionSubVPSDE` (:681-729), `DiffusionVESDE`
+(:732-766), `DiffusionGeometric` (:595-623); `make_diffusion` is upstream's factory (:18-29).  Every class keeps the reference
+constructor (`args` = cfg.sde Namespace) and `sample_discrete(...)` (:133-338).
 Schedule scalars are host-side fp32 tables computed with the reference's own op order (SURVEY hard
 part 4: var(1e-6) is exactly one ulp in fp32 and must not be recomputed with a different expf) and uploaded.
 
