@@ -61,6 +61,32 @@ def test_fullsize_teacher_forced_b64(full):
     assert rel_mse(out2[:8].cpu(), ref2) < 1e-4
 
 
+def test_fullsize_shipped_32_tokens_b64(full, monkeypatch):
+    """The shipped YAML's regime at production width: B = 64 shapes x 32 latent tokens = 2048 token rows — every GEMM on the small-tile
+    kernels (column-major tile order for the wide outputs), resident attention — teacher-forced against the oracle; and the same
+    forward with the LayerNorms folded into those kernels' epilogues (row statistics per 32 columns; opt-in, forced here)."""
+    O, cfg, score = full["O"], full["cfg"], full["score"]
+    B, T, z = 64, 32, cfg.score.z_dim
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, T, z, generator=g)
+    t = 0.61
+    monkeypatch.delenv("LDT_LN_FOLD", raising=False)
+    monkeypatch.delenv("LDT_LN_FOLD_SMALL", raising=False)
+    assert not score.can_fold(B, T)                               # the production decision for this batch: LayerNorm kernels
+    plain = score.forward_shared_t(x.cuda(), t)
+    monkeypatch.setenv("LDT_LN_FOLD", "2")
+    assert score.can_fold(B, T)
+    folded = score.forward_shared_t(x.cuda(), t)
+    monkeypatch.delenv("LDT_LN_FOLD")
+    with torch.no_grad():
+        ref = O.score_forward(full["sd_s"], cfg.score, x, torch.full((B,), t))
+    e_p, e_f = rel_mse(plain.cpu(), ref), rel_mse(folded.cpu(), ref)
+    print("full-size B=64 x 32 tokens forward rel-MSE vs oracle: LayerNorm kernels %.3e, small-tile LN folding %.3e" % (e_p, e_f))
+    assert e_p < 1e-4 and e_f < 1e-4
+    assert e_f < 4 * max(e_p, 1e-7)
+    assert not torch.equal(plain, folded)                         # the two paths really are different code
+
+
 def test_c1_exact_free_running(full):
     """BASELINE configs[0] / SURVEY §8d C1: B=4, T=256, N=100, ancestral, decode included."""
     O, cfg, tr = full["O"], full["cfg"], full["tr"]
