@@ -203,8 +203,12 @@ class Compressor(nn.Module):
         self.norm_input = cfg.norm_input
         self.pre_group = cfg.pre_group
         self.class_condition = cfg.class_condition
-        if not cfg.ActNorm or cfg.decoder_act is not None or cfg.encoder_dropout_p or cfg.decoder_dropout_p or not cfg.AdaLN:
-            raise NotImplementedError("Compressor option outside the built configurations (ActNorm off / decoder_act / dropout / AdaLN off)")
+        if not cfg.ActNorm or cfg.decoder_act is not None or not cfg.AdaLN:
+            raise NotImplementedError("Compressor option outside the built configurations (ActNorm off / decoder_act / AdaLN off)")
+        # dropout (Network.py:115-116, 148-152) is the identity under eval(), the only mode the encode / decode paths run in
+        # (trainer/Latent_SDE_Trainer.py:144-145): accepted, and checked against self.training at call time
+        self.encoder_dropout_p = float(cfg.encoder_dropout_p or 0.)
+        self.decoder_dropout_p = float(cfg.decoder_dropout_p or 0.)
         if cfg.class_condition and cfg.pos_embedding == "mlp":
             raise NotImplementedError("class_condition with pos_embedding=mlp: the reference adds a (B, p_dim) label embedding to a "
                                       "(B, p_dim, tokens) position condition (Network.py:197-198), which does not broadcast")
@@ -317,9 +321,15 @@ class Compressor(nn.Module):
 
     # ------------------------------------------------------------------ decode (Network.py:251-268)
     @torch.no_grad()
+    def _no_training_dropout(self, what):
+        if self.training and (self.encoder_dropout_p > 0 or self.decoder_dropout_p > 0):
+            raise RuntimeError("Compressor.%s: dropout configured (%g / %g) and the module is in training mode — the HIP path is the "
+                               "inference path, call eval()" % (what, self.encoder_dropout_p, self.decoder_dropout_p))
+
     def sample(self, shape, given_eps=None, keep_mask=None, seed_eps=None):
         """Top-down generation: given_eps (B, tokens, n_layers*z_dim) -> points (B, N, 3).  seed_eps: with a mixture InitialSet
         (max_outputs None), the (B, N, n_mixtures, hidden) draws of its seed rows (parity runs)."""
+        self._no_training_dropout("sample")
         B, num_points = shape[0], shape[1]
         num_points = self.outsize if num_points is None else num_points
         dev = self._device()
@@ -396,6 +406,7 @@ class Compressor(nn.Module):
         reconstruction 'set' (B, N, 3).  `post_noise`: optional list of n_layers tensors (B, tokens, z_dim) replacing
         the N(0,1) draws of `sample(mu, logvar)` (Network.py:26-29).  Training-only entries of the reference dict
         ('kls', 'all_logqz') are not produced; 'posteriors' holds token-major (mu, logvar) when want_stats."""
+        self._no_training_dropout("forward")
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("Compressor.forward: parameters on %s; the HIP path has no CPU fallback" % dev)

@@ -62,6 +62,16 @@ def test_score_block_variant_guards(tiny_cfg):
     c.AdaLN = False
     with pytest.raises(NotImplementedError, match="AdaLN: False"):
         ldt_amd.Score(c)
+    cc = copy.deepcopy(tiny_cfg.compressor)
+    cc.encoder_dropout_p = cc.decoder_dropout_p = 0.1
+    comp = ldt_amd.Compressor(cc)
+    assert comp.encoder_dropout_p == 0.1
+    comp.train()
+    with pytest.raises(RuntimeError, match="call eval"):
+        comp.sample((1, 64), given_eps=torch.zeros(1, cc.z_scales, cc.n_layers * cc.z_dim))
+    cc.decoder_act = "relu"
+    with pytest.raises(NotImplementedError):
+        ldt_amd.Compressor(cc)
 
 
 def _sde_cfg(tiny_cfg, name, a):
