@@ -8,7 +8,9 @@ ShapeNet-airplane shapes, batch 64 per GPU, 256 latent tokens x 120, 1000 ancest
 Weights are seeded random-init (no checkpoints reachable), noise is device Philox: data = synthetic.
 
     python bench.py                                  # 1 GPU, K=2 timed sample() calls after W=1 warm-up
+    python bench.py --gpus N --steps K --warmup W    # N > 1 without a launcher: starts its own ranks (a child `torch.distributed.run`)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config c5 [--gpus N]           # BASELINE configs[4]: ViPC-conditioned sampling, 32 shapes per GPU, 32 tokens
 
 Rank 0 prints ONE JSON line: metric shapes/sec (whole job) and, at N=1,
   roofline      dominant kernel of the Score forward, HIP-event timed inside this process (+ every kernel class in
@@ -23,6 +25,8 @@ import glob
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -63,19 +67,56 @@ def host_cores():
     return n
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tokens", type=int, default=256, help="latent tokens (BASELINE: 256; shipped YAML: 32)")
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--config", choices=("c2", "c5"), default="c2",
+                    help="c2 (default): BASELINE configs[1]/[2], unconditional, 64 shapes per GPU, 256 tokens; "
+                         "c5: BASELINE configs[4], ViPC-conditioned, 32 shapes per GPU, 32 tokens")
+    ap.add_argument("--tokens", type=int, default=None, help="latent tokens (c2: 256 = BASELINE, shipped YAML: 32; c5: 32)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="shapes per GPU (c2: 64; c5: 32)")
+    ap.add_argument("--force-launch", action="store_true",
+                    help="start the ranks through a child `torch.distributed.run` even at --gpus 1 (the path --gpus N > 1 takes "
+                         "when no launcher started this process)")
     ap.add_argument("--sde-steps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the C1 oracle run (cpu_baseline + parity)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] / T=32 blocks")
     ap.add_argument("--budget-s", type=float, default=540.0, help="extras are skipped once the run is older than this")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.tokens is None:
+        args.tokens = 256 if args.config == "c2" else 32
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 64 if args.config == "c2" else 32
+    return args
+
+
+def needs_self_launch(args, environ):
+    """True when this process must start the ranks itself: more than one GPU asked for (or --force-launch) and no launcher
+    (torch.distributed.run sets RANK) started us."""
+    return "RANK" not in environ and (args.gpus > 1 or args.force_launch)
+
+
+def launcher_argv(argv, gpus, port):
+    """The command `python bench.py --gpus N ...` runs as a CHILD when no launcher started it: one rank per GPU of this node
+    under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    rest = [a for a in argv if a != "--force-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def self_launch(args, argv):
+    """Start the ranks as a child process and relay its output.  Runs BEFORE anything in this process touches the GPU (never exec
+    from a process that initialised HIP); the child's single JSON line passes through on stdout, its return code is ours."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launcher_argv(argv, args.gpus, port)
+    log("no launcher in the environment: starting %d rank(s): %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def score_flops_per_sample_step(cfg):
@@ -298,13 +339,21 @@ def c1_baseline_and_parity(trainer, cfg_full):
 
 
 # ----------------------------------------------------------------------------------------------------------- extras
-def _timed(fn, reps=2):
+def _timed(fn, reps=2, stats=None):
+    """seconds per call (median over `reps` individually synchronised calls after one warm-up) and the last result;
+    `stats` (a dict) receives min / max / reps."""
     fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         r = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps, r
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    if stats is not None:
+        stats.update(reps=reps, min_s=ts[0], max_s=ts[-1], median_s=med)
+    return med, r
 
 
 def extra_c4(tokens=256, batch=1024, chunk=1024):
@@ -324,8 +373,9 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
     pts_h = pts_h - pts_h.mean(1, keepdim=True)
     pts_h = pts_h / pts_h.norm(dim=-1).amax(1)[:, None, None]
     pts = pts_h.cuda()
-    t_enc, eps = _timed(lambda: torch.cat([comp(pts[i:i + chunk])["all_eps"] for i in range(0, batch, chunk)]))
-    t_dec, dec = _timed(lambda: comp.sample((batch, 2048), given_eps=eps))
+    st_enc, st_dec = {}, {}
+    t_enc, eps = _timed(lambda: torch.cat([comp(pts[i:i + chunk])["all_eps"] for i in range(0, batch, chunk)]), reps=12, stats=st_enc)
+    t_dec, dec = _timed(lambda: comp.sample((batch, 2048), given_eps=eps), reps=12, stats=st_dec)
     assert bool(torch.isfinite(dec).all())
     cc = cfg.compressor
     d, L, T = cc.hidden_dim, cc.n_layers, tokens
@@ -385,6 +435,9 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
     return {"workload": "BASELINE configs[3]: Compressor encode+decode only, batch %d, 2048 pts <-> %d tokens, 1 GPU" % (batch, T),
             "encode_clouds_per_s": round(batch / t_enc, 1), "decode_clouds_per_s": round(batch / t_dec, 1),
             "encode_decode_clouds_per_s": round(batch / (t_enc + t_dec), 1),
+            "timing": {"what": "median of 12 individually synchronised calls after one warm-up call; clouds/s at the slowest / fastest call",
+                       "encode_clouds_per_s_min_max": [round(batch / st_enc["max_s"], 1), round(batch / st_enc["min_s"], 1)],
+                       "decode_clouds_per_s_min_max": [round(batch / st_dec["max_s"], 1), round(batch / st_dec["min_s"], 1)]},
             "decode_roofline": {"bound": "mfma", "achieved": round(dec_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(dec_tf / PEAK_BF16_TFLOPS, 4), "flops_per_cloud": dec_flops},
             "decode_unfused_lower_bound": {"what": "7 kernels per block each reading + writing the fp32 (2048 x %d) set at 8 TB/s" % d,
@@ -455,30 +508,38 @@ def extra_sampling(score, tokens, batch, n_steps, vipc, cpu_steps=6):
         D, L = cfg.score.hidden_size, cfg.score.num_blocks
         flops += 2.0 * (L * 6 * D + 2 * D) * cfg.score.t_dim * n_steps * batch
     tf = flops / dt / 1e12
-    # bounded CPU sample
-    torch.set_num_threads(host_cores())
-    sd_s = {k: v.detach().float().cpu() for k, v in score.state_dict().items()}
-    Bc = 4
-    x0, noises = O.draw_noises(7, Bc, tokens, cfg.score.z_dim, cpu_steps)
-    sde = O.VPSDE(cfg.sde)
-    cnd = None if not vipc else (cond[0][:Bc].cpu().transpose(1, 2).contiguous(), cond[1][:Bc].cpu())
-    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd_s, cfg.score, x, t, condition=cnd))
-    with torch.no_grad():
-        t0 = time.time()
-        O.sample_discrete(sde, fn, x0, noises, n_steps, max_steps=cpu_steps)
-        t_step = (time.time() - t0) / cpu_steps
+    base, sd_s = bounded_cpu_baseline(score, cfg, tokens, n_steps, cond, cpu_steps)
     par = vipc_parity(score, tokens, batch, cond, sd_s) if vipc else None
     return {**({"parity": par} if par else {}),
             "shapes_per_s": round(batch / dt, 3), "ms_per_sde_step": round(1e3 * dt / n_steps, 3), "seconds_per_call": round(dt, 3),
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                          "scope": "whole job (Score flops of SURVEY §8d / wall time)"},
-            "cpu_baseline": {"value": Bc / (n_steps * t_step), "unit": "shapes/sec", "cores": host_cores(), "kind": "port",
-                             "sample": "oracle, B=%d, T=%d, first %d of %d steps (%.3f s/step), extrapolated linearly, decode excluded"
-                                       % (Bc, tokens, cpu_steps, n_steps, t_step)}}
+            "cpu_baseline": base}
+
+
+def bounded_cpu_baseline(score, cfg, tokens, n_steps, cond, cpu_steps=6, Bc=4):
+    """CPU oracle on a bounded sample of a sampling workload: B = 4 shapes, the first `cpu_steps` SDE steps (the loop body is
+    step-invariant), extrapolated linearly to `n_steps`; decode excluded.  `cond` = the GPU run's (pts, img) condition or None."""
+    from oracle import ldt_oracle as O
+    torch.set_num_threads(host_cores())
+    sd_s = {k: v.detach().float().cpu() for k, v in score.state_dict().items()}
+    x0, noises = O.draw_noises(7, Bc, tokens, cfg.score.z_dim, cpu_steps)
+    sde = O.VPSDE(cfg.sde)
+    cnd = None if cond is None else (cond[0][:Bc].cpu().transpose(1, 2).contiguous(), cond[1][:Bc].cpu())
+    fn = O.score_fn_from_model(sde, lambda x, t: O.score_forward(sd_s, cfg.score, x, t, condition=cnd))
+    with torch.no_grad():
+        t0 = time.time()
+        O.sample_discrete(sde, fn, x0, noises, n_steps, max_steps=cpu_steps)
+        t_step = (time.time() - t0) / cpu_steps
+    return {"value": Bc / (n_steps * t_step), "unit": "shapes/sec", "cores": host_cores(), "kind": "port",
+            "sample": "oracle, B=%d, T=%d, first %d of %d steps (%.3f s/step), extrapolated linearly, decode excluded"
+                      % (Bc, tokens, cpu_steps, n_steps, t_step)}, sd_s
 
 
 def main():
     args = parse()
+    if needs_self_launch(args, os.environ):              # before ANY GPU call in this process
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -499,6 +560,12 @@ def main():
     comp.init()
     trainer = ldt_amd.Trainer(cfg, score, comp, device)
     B = args.batch_per_gpu * world
+    cond, S = None, 32
+    if args.config == "c5":
+        # BASELINE configs[4]: synthetic ConditionNet outputs for the GLOBAL batch (pts_condition ~ N(0,1) (B, hidden, S),
+        # img_condition ~ N(0,1) (B, t_dim)), drawn identically on every rank; Trainer.sample hands each rank its rows
+        g = torch.Generator().manual_seed(5)
+        cond = (torch.randn(B, cfg.score.hidden_size, S, generator=g).to(device), torch.randn(B, cfg.score.t_dim, generator=g).to(device))
 
     def barrier():
         if launched:
@@ -507,13 +574,13 @@ def main():
 
     log("model built on %s (world %d), B=%d T=%d N=%d" % (device, world, B, args.tokens, args.sde_steps))
     for i in range(args.warmup):
-        trainer.sample(B)
+        trainer.sample(B, condition=cond)
         torch.cuda.synchronize()
         log("warmup %d done" % i)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pts, eps = trainer.sample(B)
+        pts, eps = trainer.sample(B, condition=cond)
     barrier()
     dt = time.perf_counter() - t0
     log("timed region: %.2f s for %d sample() calls" % (dt, args.steps))
@@ -526,35 +593,50 @@ def main():
     if rank == 0:
         value = B * args.steps / dt
         flops_call = score_flops_per_sample_step(cfg) * args.sde_steps * B
+        if cond is not None:                             # + per-sample AdaLN rows (6 D t_dim per block + final) per sample-step
+            flops_call += 2.0 * (cfg.score.num_blocks * 6 * cfg.score.hidden_size + 2 * cfg.score.hidden_size) * cfg.score.t_dim * args.sde_steps * B
+        wl = ("BASELINE configs[1]: ShapeNet-airplane sampling, batch %d/GPU, %d latent tokens x %d, %d ancestral SDE steps (24-block d=1024 Score) "
+              "+ decode to %d points" if cond is None else
+              "BASELINE configs[4]: ViPC-conditioned sampling (synthetic ConditionNet outputs: 32 condition tokens + image vector per shape), "
+              "batch %d/GPU, %d latent tokens x %d, %d ancestral SDE steps (24-block d=1024 Score, per-sample AdaLN, cross-attention on even "
+              "blocks) + decode to %d points") % (args.batch_per_gpu, args.tokens, cfg.score.z_dim, args.sde_steps, cfg.data.tr_max_sample_points)
         line = {
             "metric": "shapes/sec (2048-pt, %d-step SDE sample)" % args.sde_steps, "value": round(value, 4),
             "unit": "shapes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ShapeNet-airplane sampling, batch %d/GPU, %d latent tokens x %d, "
-                                   "%d ancestral SDE steps (24-block d=1024 Score) + decode to %d points"
-                                   % (args.batch_per_gpu, args.tokens, cfg.score.z_dim, args.sde_steps, cfg.data.tr_max_sample_points),
+            "config": {"workload": wl, "name": args.config,
                        "global_batch": B, "batch_per_gpu": args.batch_per_gpu, "latent_tokens": args.tokens,
                        "sde_steps": args.sde_steps, "points": cfg.data.tr_max_sample_points,
                        "parallelism": "dp%d batch slices, one all-gather" % world,
-                       "collective": ("%s, world %d" % (dist.get_backend(), world)) if launched else "none (single process)"},
+                       "collective": ("%s, world %d" % (dist.get_backend(), dist.get_world_size())) if launched else "none (single process)"},
             "achieved_tflops_whole_job": round(flops_call * args.steps / dt / 1e12, 1),
             "whole_job_mfma_frac": round(flops_call * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
-        if not args.no_roofline:
+        if not args.no_roofline and cond is None:
             roof, roofs, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
             log("roofline pass done: %s" % json.dumps(kernels))
             line["roofline"] = roof
             line["roofline_attention"] = roofs.get("attention")
             line["roofline_kernels"] = roofs
             line["kernels"] = kernels
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cond is None:
             base, parity = c1_baseline_and_parity(trainer, cfg)
             line["cpu_baseline"] = base
             line["parity"] = parity
             line["speedup_vs_cpu"] = round(value / base["value"], 1)
             log("parity: %s" % json.dumps({k: parity[k] for k in ("per_step_max", "final_latent", "chamfer_norm", "pass")}))
-        if world == 1 and not args.no_extras:
+        if cond is not None:                             # configs[4]: whole-job roofline; bounded oracle baseline + full-width parity at N = 1
+            tf = flops_call * args.steps / dt / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                "scope": "whole job (Score flops of SURVEY §8d + per-sample AdaLN rows / wall time); per-kernel rooflines: --config c2"}
+            if world == 1 and not args.no_cpu_baseline:
+                base, sd_s = bounded_cpu_baseline(score, cfg, args.tokens, args.sde_steps, cond)
+                line["cpu_baseline"] = base
+                line["parity"] = vipc_parity(score, args.tokens, B, cond, sd_s)
+                line["speedup_vs_cpu"] = round(value / base["value"], 1)
+        if world == 1 and not args.no_extras and cond is None:
             extra = {}
             for name, fn in (("c4_compressor_b1024", lambda: extra_c4()),
                              ("c5_vipc_share_b32_t32", lambda: dict(workload="BASELINE configs[4] per-GPU share: ViPC-conditioned sampling, 32 shapes/GPU, "

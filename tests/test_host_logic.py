@@ -1,11 +1,12 @@
 """CPU: host-side logic of the drop-in classes (no kernel launches)."""
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_mse
+from conftest import ROOT, load_golden, rel_mse
 
 
 def test_state_dict_names_and_shapes_match_reference(tiny_cfg):
@@ -476,3 +477,33 @@ def test_valsample_has_the_reference_signature_and_loader_semantics(tiny_cfg, tm
     assert tr.valsample(2, batch_size=4, save_npy=False) == {} and [c[0] for c in calls] == [4, 4]
     with pytest.raises(ValueError):
         tr.valsample(1, batch_size=2, save_npy=True)
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher in the environment starts `torch.distributed.run` as a CHILD process before
+    touching the GPU and relays its return code; under a launcher (RANK set) it runs as a rank."""
+    import bench
+    args = bench.parse(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert bench.needs_self_launch(args, {}) and not bench.needs_self_launch(args, {"RANK": "0", "WORLD_SIZE": "2"})
+    assert not bench.needs_self_launch(bench.parse(["--gpus", "1"]), {})
+    assert bench.needs_self_launch(bench.parse(["--gpus", "1", "--force-launch"]), {})
+    argv = bench.launcher_argv(["--gpus", "2", "--steps", "3", "--warmup", "1", "--force-launch"], 2, 29555)
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "2" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[argv.index("--master-port") + 1] == "29555"
+    tail = argv[argv.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "2", "--steps", "3", "--warmup", "1"]              # same arguments, the launch flag dropped
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7 and calls["cmd"][-2:] == ["--gpus", "2"] and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    c5 = bench.parse(["--config", "c5"])
+    assert (c5.tokens, c5.batch_per_gpu) == (32, 32) and bench.parse([]).tokens == 256 and bench.parse([]).batch_per_gpu == 64
