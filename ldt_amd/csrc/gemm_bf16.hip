@@ -1269,6 +1269,17 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
                     LDT_EARG, "gemm: gate needs rows_per_sample>0 and 16-byte aligned strides");
     }
     LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm: bias must be 16-byte aligned");
+    if (gemm_variant() == 0) {
+        // mid-size problems (gemm_mid.hip): 128 x 256 / 128 x 128 tiles with dedicated loader waves, when the 256^2 persistent kernel would
+        // leave CUs idle (its 5/8 rule below) — the 1-4k-row batches; also their split-K partials
+        const int t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+        const int lim = (a->max_wgs > 0 && a->max_wgs < LDT_NUM_CUS) ? a->max_wgs : LDT_NUM_CUS;
+        const bool big = t256 * 8 >= lim * 5 && a->N > 128 && a->splits <= 1;
+        if (!big) {
+            const int bn = ldt_gemm_mid_bn(epi, a);
+            if (bn) return ldt_gemm_mid_launch(epi, bn, a, stream);
+        }
+    }
     if (a->splits > 1) {
         // split-K (small-M regime: the residual GEMMs of a 1-2k-row batch have too few output tiles to fill 256 CUs with a tile large
         // enough to keep the operand stream under the L2 -> LDS rate): fp32 partial tiles, reduced by the consumer (ldt_ln_launch)

@@ -69,6 +69,47 @@ def test_gemm_all_epilogues(M, N, K):
     assert rel_mse(rd.cpu(), resid.double() + ref) < 1e-9
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 1024), (2048, 3072, 1024), (2048, 1024, 4096), (1024, 4096, 1024), (1024, 1024, 1024),
+                                   (2048, 4096, 64), (2048, 4096, 128), (2048, 4096, 192), (1152, 1536, 64), (1152, 1536, 192),
+                                   (1000, 2304, 320), (1960, 4096, 320), (4096, 1024, 1024)])
+def test_gemm_mid_kernel(M, N, K):
+    """The mid-size tile kernel (csrc/gemm_mid.hip: 128 x 256 / 128 x 128 tiles, loader waves, 3-stage ring) on the shapes the launcher hands
+    it — incl. 1 / 2 / 3 / 5 K-tiles (prologue and drain paths of the ring), a ragged last row tile, a step-indexed shared gate, a per-sample
+    gate and split-K partials — vs fp64 on the same bf16 operands."""
+    from ldt_amd._lib import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + bias.double()
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(bias)
+    assert rel_mse(ops.gemm_bf16(xd, wd, bd, EPI_F32).cpu(), ref) < 1e-9
+    o1 = ops.gemm_bf16(xd, wd, bd, EPI_BF16)
+    assert rel_mse(o1.float().cpu(), ref) < 1e-5
+    assert torch.equal(o1, ops.gemm_bf16(xd, wd, bd, EPI_BF16))                  # no race: identical twice
+    assert rel_mse(ops.gemm_bf16(xd, wd, bd, EPI_GELU_BF16).float().cpu(), torch.nn.functional.gelu(ref)) < 1e-5
+    resid = torch.randn(M, N, generator=g)
+    # shared gate picked by a device-side step counter (unconditional sampling: mod[step][...])
+    gates = torch.randn(3, 2 * N, generator=g)
+    step = torch.tensor([2], dtype=torch.int32, device="cuda")
+    rd = dev(resid.clone())
+    ops.gemm_bf16(xd, wd, bd, EPI_RESID_F32, out=rd, resid=rd, gate=dev(gates)[:, N:], gate_sample_stride=0, rows_per_sample=M,
+                  step_ptr=step, gate_step_stride=2 * N)
+    assert rel_mse(rd.cpu(), resid.double() + gates[2, N:].double() * ref) < 1e-9
+    # per-sample gate (conditional sampling), rows_per_sample = 8
+    if M % 8 == 0:
+        gate = torch.randn(M // 8, 3 * N, generator=g)
+        rd = dev(resid.clone())
+        ops.gemm_bf16(xd, wd, bd, EPI_RESID_F32, out=rd, resid=rd, gate=dev(gate)[:, N:2 * N], gate_sample_stride=3 * N, rows_per_sample=8)
+        assert rel_mse(rd.cpu(), resid.double() + gate[:, N:2 * N].double().repeat_interleave(8, 0) * ref) < 1e-9
+    for splits in (2, 4):
+        if K % (splits * 64) == 0:
+            parts = ops.gemm_bf16_splitk(xd, wd, splits)
+            assert parts.shape == (splits, M, N)
+            assert rel_mse(parts.sum(0).cpu(), x.double() @ w.double().T) < 1e-9
+            ks = K // splits
+            assert rel_mse(parts[1].cpu(), x[:, ks:2 * ks].double() @ w[:, ks:2 * ks].double().T) < 1e-9
+
+
 @pytest.mark.parametrize("M,D,N2,gelu,granule", [(512, 1024, 768, False, 256), (256, 512, 2048, True, 256), (768, 256, 256, False, 256),
                                                  (66560, 256, 256, True, 256),     # 260 tiles: persistent workgroups take a 2nd tile
                                                  # the small-batch kernels (statistics per 32 columns): 64x64 and 128x64 tile forms
