@@ -1238,7 +1238,11 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
         LDT_REQUIRE(a->xs && a->ln_scale && a->stats_out && a->ldxs % 4 == 0 && a->ldxs >= a->N && ldt_aligned16(a->xs) &&
                     ldt_aligned16(a->ln_scale) && a->ln_step_stride % 4 == 0 && ldt_aligned16(a->stats_out), LDT_EARG,
                     "gemm_lnfold: producer needs xs / ln_scale / stats_out (16-byte aligned)");
-        if (v1) return launch_v1_fold<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
+        if (v1) {
+            int st = LDT_OK;
+            if (gemm_variant_env() == 0 && ldt_gemm_mid_lnfold_try(EPI_RESID_F32, a, stream, &st)) return st;   // mid-size tile kernel (gemm_mid.hip)
+            return launch_v1_fold<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
+        }
         return launch_256<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
     }
     LDT_REQUIRE(epi == EPI_BF16 || epi == EPI_GELU_BF16, LDT_EARG, "gemm_lnfold: epilogue %d has no folded form", epi);
@@ -1246,6 +1250,8 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
                 a->fold_step_stride % 4 == 0, LDT_EARG, "gemm_lnfold: consumer needs stats_in, fold_S, fold_C (16-byte aligned)");
     if (v1) {
         LDT_REQUIRE(a->stats_parts <= 32, LDT_ESHAPE, "gemm_lnfold (v1 route): K=%d > 1024 input channels", a->K);
+        int st = LDT_OK;
+        if (gemm_variant_env() == 0 && ldt_gemm_mid_lnfold_try(epi, a, stream, &st)) return st;
         return epi == EPI_BF16 ? launch_v1_fold<EPI_BF16, FOLD_CONSUMER>(a, stream) : launch_v1_fold<EPI_GELU_BF16, FOLD_CONSUMER>(a, stream);
     }
     LDT_REQUIRE(a->stats_parts >= 1 && a->stats_parts <= 4 && a->stats_parts * 256 == a->K, LDT_EARG,
@@ -1276,8 +1282,8 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
         const int lim = (a->max_wgs > 0 && a->max_wgs < LDT_NUM_CUS) ? a->max_wgs : LDT_NUM_CUS;
         const bool big = t256 * 8 >= lim * 5 && a->N > 128 && a->splits <= 1;
         if (!big) {
-            const int bn = ldt_gemm_mid_bn(epi, a);
-            if (bn) return ldt_gemm_mid_launch(epi, bn, a, stream);
+            const int shape = ldt_gemm_mid_shape(epi, a);
+            if (shape) return ldt_gemm_mid_launch(epi, shape, a, stream);
         }
     }
     if (a->splits > 1) {

@@ -36,21 +36,35 @@
 
 #include "kernels.h"
 
-#define MID_BM 128
 #define MID_BK 64
-#define MID_NS 3
-#define MID_XB (MID_BM * MID_BK * 2)                     /* 16 KiB: X part of a stage */
 
-template <int BN>
+// BM x BN output tile: 128 x 256 (the widest a CU's LDS and the accumulator budget take), 128 x 128, and 64 x 128 for the N = hidden
+// residual GEMMs of a 2k-row batch (256 workgroups instead of 128; the smaller stage buys a 4-deep ring)
+template <int BM, int BN>
 struct MidCfg {
-    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (wave = BN / 4 columns)
-    static constexpr int STAGE = MID_XB + BN * MID_BK * 2;
-    static constexpr int RING = MID_NS * STAGE;
+    static constexpr int MT = BM / 16;                   // 16-row accumulator tiles per compute wave (a wave spans all BM rows)
+    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (a wave = BN / 4 columns)
+    static constexpr int XB = BM * MID_BK * 2;           // X part of a stage (bytes)
+    static constexpr int STAGE = XB + BN * MID_BK * 2;
+    static constexpr int NS = BM == 64 ? 4 : 3;          // ring stages
+    static constexpr int RING = NS * STAGE;
     static constexpr int LDS = RING + 4 * 4096;
-    static constexpr int XPW = MID_BM / 8 / 4;           // X pieces per loader wave and K-tile (4)
-    static constexpr int WPW = BN / 8 / 4;               // W pieces per loader wave and K-tile (8 | 4)
+    static constexpr int XPW = BM / 8 / 4;               // X pieces per loader wave and K-tile
+    static constexpr int WPW = BN / 8 / 4;               // W pieces per loader wave and K-tile
     static constexpr int PPW = XPW + WPW;
 };
+
+// LN folding (gemm_bf16.hip "LN folding"; statistics granule = 32 columns = a compute wave's share of a 128-wide tile, plan->stats[D / 32][M][2]):
+//   MID_FOLD_PRODUCER (EPI_RESID_F32, BN = 128): the epilogue also stores xs = bf16(x_new (1 + ln_scale)) and the wave's per-row (sum, sum of
+//     squares) over its 32 columns -> stats_out[n / 32][M][2] (8-lane DPP row sums in a fixed order: bit-reproducible, no atomics);
+//   MID_FOLD_CONSUMER (EPI_BF16 / EPI_GELU_BF16): X = xs.  The LOADER waves — idle between issue bursts — fetch the tile's rows' K / 32 partials
+//     and its S | C slices behind the first ring fill, form (rstd, -mean rstd) per row and leave both in the tails of the staging areas; the
+//     compute waves' epilogue is y = rstd acc + (-mean rstd S + C).
+enum { MID_FOLD_NONE = 0, MID_FOLD_PRODUCER = 1, MID_FOLD_CONSUMER = 2 };
+#define MID_TAIL_OFF 2304            /* bf16 staging uses at most 16 rows x 144 B of each compute wave's 4 KiB; the tails hold: */
+#define MID_RS_OFF (0 * 4096 + MID_TAIL_OFF)     /* (rstd, -mean rstd) of the tile's <= 128 rows (1 KiB)  */
+#define MID_S_OFF (1 * 4096 + MID_TAIL_OFF)      /* fold_S slice, BN floats (<= 1 KiB)                    */
+#define MID_C_OFF (2 * 4096 + MID_TAIL_OFF)      /* fold_C slice                                          */
 
 #define MID_BARRIER()                         \
     do {                                      \
@@ -62,14 +76,14 @@ struct MidCfg {
 // Instruction order of one 16-MFMA block and the R fragment reads issued for the NEXT block (one compute wave per SIMD: nothing else
 // fills the matrix pipe while this wave issues ds_reads, ~16 cycles each, so they go BETWEEN the MFMAs): R x (1 read, MPR MFMAs), then
 // the remaining MFMAs — the reads lead, so the block after this one does not open on an LDS round trip.
-template <int R, int MPR>
+template <int R, int MPR, int TOTAL = 16>
 __device__ __forceinline__ void mid_interleave() {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
         __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);     // MFMA
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 - R * MPR, 0);
+    if constexpr (TOTAL - R * MPR > 0) __builtin_amdgcn_sched_group_barrier(0x008, TOTAL - R * MPR, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -94,9 +108,9 @@ extern "C" int ldt_dbg_mid_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 #endif
 
 // ---------------------------------------------------------------------------------------------- loader waves
-template <int BN>
-__device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw, int lane, int m0, int n0, int kbase, int nkt) {
-    using C = MidCfg<BN>;
+template <int BM, int BN, int FOLD>
+__device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw, int lane, int m0, int n0, int kbase, int nkt, int step) {
+    using C = MidCfg<BM, BN>;
     // piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7)
     const char* xp[C::XPW];
     const char* wp[C::WPW];
@@ -125,7 +139,7 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
 #pragma unroll
         for (int q = 0; q < C::WPW; ++q) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wp[q],
-                                             (__attribute__((address_space(3))) void*)(st + MID_XB + (lw * C::WPW + q) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + C::XB + (lw * C::WPW + q) * 1024), 16, 0, 0);
             wp[q] += MID_BK * 2;
         }
     };
@@ -134,24 +148,89 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
     issue(0);
     if (nkt > 1) issue(1);
     MID_STAMP(1);
-    // K-tile 0 landed (K-tile 1 may still be in flight); K-tile 2 follows the barrier: the compute waves start one K-tile's issue time earlier
+    // K-tile 0 landed (K-tile 1 may still be in flight); the rest of the ring follows the barrier: the compute waves start earlier
     if (nkt > 1) mid_wait_vmcnt<C::PPW>();
     else mid_wait_vmcnt<0>();
     MID_STAMP(2);
     MID_BARRIER();                                       // prologue barrier
     MID_STAMP(3);
-    if (nkt > 2) issue(2);
+#pragma unroll
+    for (int j = 2; j < C::NS; ++j)
+        if (j < nkt) issue(j);
     int slot = 0;
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
+    int kt0 = 0;
+    if constexpr (FOLD == MID_FOLD_CONSUMER) {
+        // (launcher: nkt >= NS + 2, so the whole ring is in flight and K-tile NS exists)  Behind the ring fill: this tile's row statistics
+        // (BM rows x stats_parts <= 32 partials: thread t -> row t / TPR, a contiguous run of partials) and S | C slices (one LDS-DMA per wave).
+        constexpr int TPR = 256 / BM, PPT = 32 / TPR, NSTAT = PPT + 1;
+        const int t = lw * 64 + lane;
+        int row = m0 + t / TPR;
+        row = row < a.M ? row : a.M - 1;
+        const int p0 = (t % TPR) * PPT;
+        const float* sp = a.stats_in + (long)row * 2;
+        static_assert(PPT == 16, "the statistics pass is written for 128-row tiles (16 partials per thread)");
+        // The partials are loaded by asm statements hipcc does not count: beside LDS-DMA requests it drains the whole queue (vmcnt(0)) before
+        // and after any register load it knows of (cdna_hip_programming.md §5 trap 4b), which would park this wave until the ring has landed.
+        // Their completion is counted by hand below; the wait statement names every destination (§5.7 item 1, form ii).
+        f32x2 part[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {                  // (clamped, never branched: partials past stats_parts are re-reads of the last one, masked below)
+            const int p = p0 + i < a.stats_parts ? p0 + i : a.stats_parts - 1;
+            const float* src = sp + (long)p * a.M * 2;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(part[i]) : "v"(src) : "memory");
+        }
+        {
+            constexpr int Q = 2 * BN;                    // bytes of [S | C] per loader wave: waves 0, 1 -> S, waves 2, 3 -> C
+            const long fst = (long)step * a.fold_step_stride;
+            const float* src = (lw < 2 ? a.fold_S : a.fold_C) + fst + n0 + (lw & 1) * (Q / 4) + lane * 4;
+            char* dst = smem + C::RING + (lw < 2 ? MID_S_OFF : MID_C_OFF) + (lw & 1) * Q;
+            if (lane * 16 < Q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        // barrier 0: K-tile 1 landed — issued after it: K-tiles 2 .. NS-1 and the NSTAT requests above
+        mid_wait_vmcnt<(C::NS - 2) * C::PPW + NSTAT>();
+        MID_BARRIER();
+        issue(0);                                        // K-tile NS -> stage 0
+        slot = 1;
+        // everything older than K-tile NS's pieces — the statistics and S | C — has landed
+        asm volatile("s_waitcnt vmcnt(%16)"
+                     : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7]),
+                       "+v"(part[8]), "+v"(part[9]), "+v"(part[10]), "+v"(part[11]), "+v"(part[12]), "+v"(part[13]), "+v"(part[14]), "+v"(part[15])
+                     : "n"(C::PPW) : "memory");
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (p0 + i < a.stats_parts) { s1 += part[i][0]; s2 += part[i][1]; }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {              // partner threads are adjacent lanes: lower run + upper run, fixed order
+            const float o1 = __shfl_xor(s1, o, 64), o2 = __shfl_xor(s2, o, 64);
+            s1 = (t & o) ? o1 + s1 : s1 + o1;
+            s2 = (t & o) ? o2 + s2 : s2 + o2;
+        }
+        if (t % TPR == 0) {
+            const float invk = 1.0f / (float)a.K;
+            const float mean = s1 * invk;
+            const float var = fmaxf(s2 * invk - mean * mean, 0.f);
+            const float r = rsqrtf(var + 1e-6f);
+            *reinterpret_cast<f32x2*>(smem + C::RING + MID_RS_OFF + (t / TPR) * 8) = (f32x2){r, -mean * r};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to the compute waves behind barrier 1 (they read it after the main loop)
+        kt0 = 1;
+    }
+    for (int kt = kt0; kt + 1 < nkt; ++kt) {
         MID_STAMP(4 + 3 * kt);
-        // K-tile kt+1 landed (only K-tile kt+2, if it exists, was issued after it; kt+3 is issued past the barrier)
-        if (kt + 2 < nkt) mid_wait_vmcnt<C::PPW>();
+        // K-tile kt+1 landed: the K-tiles issued after it are kt+2 .. min(kt + NS - 1, nkt - 1) (kt + NS goes out past the barrier)
+        const int last = kt + C::NS - 1 < nkt - 1 ? kt + C::NS - 1 : nkt - 1;
+        const int ahead = last - (kt + 1);               // 0 .. NS - 2
+        if (ahead >= 2) mid_wait_vmcnt<2 * C::PPW>();
+        else if (ahead == 1) mid_wait_vmcnt<C::PPW>();
         else mid_wait_vmcnt<0>();
         MID_STAMP(5 + 3 * kt);
         MID_BARRIER();                                   // barrier kt: compute waves are past their last read of K-tile kt
         MID_STAMP(6 + 3 * kt);
-        if (kt + 3 < nkt) issue(slot);                   // K-tile kt+3 -> the stage K-tile kt has left
-        slot = slot + 1 == MID_NS ? 0 : slot + 1;
+        if (kt + C::NS < nkt) issue(slot);               // K-tile kt+NS -> the stage K-tile kt has left
+        slot = slot + 1 == C::NS ? 0 : slot + 1;
     }
 #ifdef MID_STAMPS
     if (lw == 0) MID_STAMP_FLUSH(1);
@@ -169,27 +248,51 @@ __device__ __forceinline__ f32x4 mid_resid_load(const GemmArgs& a, int m0, int n
     return *reinterpret_cast<const f32x4*>(a.resid + row * a.ldr + nb + (lane % CPR) * 4);
 }
 
-// `rpre` (EPI_RESID_F32, BN = 128): the wave's whole residual tile, requested before the main loop (16 x 16 B per lane)
-template <int EPI, int BN>
-__device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[MidCfg<BN>::NT][8], int m0, int nb, int lane, char* reg,
-                                             const f32x4 (&rpre)[8][2]) {
-    constexpr int NT = MidCfg<BN>::NT;
+// `rpre` (EPI_RESID_F32, BN = 128): the wave's whole residual tile, requested before the main loop (2 x 16 B per lane and 16-row pass)
+// sum over the 8 lanes of an aligned lane octet (all 8 end up with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float mid_oct_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+template <int EPI, int BM, int BN, int FOLD>
+__device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[MidCfg<BM, BN>::NT][MidCfg<BM, BN>::MT], int m0, int nb, int wn, int lane,
+                                             char* reg, const char* stage_base, const f32x4 (&rpre)[MidCfg<BM, BN>::MT][2], int step) {
+    constexpr int NT = MidCfg<BM, BN>::NT, MT = MidCfg<BM, BN>::MT;
     const int lrow = lane & 15, lchk = lane >> 4;
     f32x4 bias4[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
-        bias4[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bias4[ni] = (a.bias && FOLD != MID_FOLD_CONSUMER) ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
         constexpr int RS = NT * 32 + 16;                 // staged row: NT*16 bf16 + 16 B pad
         constexpr int CPR = NT * 2;                      // 16-B chunks per row (8 | 4)
         constexpr int RPI = 64 / CPR;                    // rows per store instruction (8 | 16)
+        f32x4 s4[NT];
+        if constexpr (FOLD == MID_FOLD_CONSUMER) {       // this wave's columns of the S | C slices the loader waves left in the staging tails
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+            for (int ni = 0; ni < NT; ++ni) {
+                const int c = wn * (BN / 4) + ni * 16 + lchk * 4;
+                s4[ni] = *reinterpret_cast<const f32x4*>(stage_base + MID_S_OFF + c * 4);
+                bias4[ni] = *reinterpret_cast<const f32x4*>(stage_base + MID_C_OFF + c * 4);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            f32x2 rn = {1.f, 0.f};
+            if constexpr (FOLD == MID_FOLD_CONSUMER) rn = *reinterpret_cast<const f32x2*>(stage_base + MID_RS_OFF + (mi * 16 + lrow) * 8);
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 f32x4 v = acc[ni][mi];
+                if constexpr (FOLD == MID_FOLD_CONSUMER) {   // y = rstd acc + (-mean rstd S + C): the bias is inside C
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                    for (int r = 0; r < 4; ++r) v[r] = rn[0] * v[r] + (rn[1] * s4[ni][r] + bias4[ni][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bias4[ni][r];
+                }
                 if constexpr (EPI == EPI_GELU_BF16) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
@@ -214,12 +317,18 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
         constexpr int RSB = CPR * 16;                    // staged row bytes (256 | 128), chunk index XORed with the row
         const int ch = lane % CPR;
         const float* gate = a.gate;
-        if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
+        if (EPI == EPI_RESID_F32 && gate) gate += (long)step * a.gate_step_stride;
         const bool has_gate = (EPI == EPI_RESID_F32) && gate;
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
         f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
         if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
         float* obase = reinterpret_cast<float*>(a.out) + ((EPI == EPI_F32 && a.splits > 1) ? (long)blockIdx.y * a.split_stride : 0L);
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (FOLD == MID_FOLD_PRODUCER) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.ln_scale + (long)step * a.ln_step_stride + nb + ch * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc4[r] = 1.0f + t[r];
+        }
         // BN = 256: the residual rows are requested TWO passes ahead (a pass = 16 rows = 4 x 16 B per lane; the fragment registers of the
         // main loop are free by now) — loaded pass by pass, each pass would expose a whole memory round trip (8 x ~1.3 us from HBM)
         constexpr int AHEAD = 2;
@@ -235,7 +344,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
         auto passes = [&](auto per_sample_c) {
             constexpr bool PER_SAMPLE = decltype(per_sample_c)::value;
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
+            for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni) {
                     f32x4 v = acc[ni][mi];
@@ -252,17 +361,26 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
                     if constexpr (EPI == EPI_RESID_F32) {
                         if constexpr (NT == 4) {
                             x = rq[mi % AHEAD][it];
-                            if (mi + AHEAD < 8) rq[mi % AHEAD][it] = mid_resid_load<NT>(a, m0, nb, lane, mi + AHEAD, it);
+                            if (mi + AHEAD < MT) rq[mi % AHEAD][it] = mid_resid_load<NT>(a, m0, nb, lane, mi + AHEAD, it);
                         } else x = rpre[mi][it];
                     }
-                    if (mrow0 + row >= a.M) continue;
+                    const bool live = mrow0 + row < a.M;
                     if constexpr (EPI == EPI_RESID_F32) {
-                        if constexpr (PER_SAMPLE)
-                            g4 = *reinterpret_cast<const f32x4*>(gate + ((mrow0 + row) / a.rows_per_sample) * a.gate_sample_stride + nb + ch * 4);
+                        if constexpr (PER_SAMPLE) {
+                            const long srow = live ? mrow0 + row : (long)a.M - 1;
+                            g4 = *reinterpret_cast<const f32x4*>(gate + (srow / a.rows_per_sample) * a.gate_sample_stride + nb + ch * 4);
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                     }
-                    *reinterpret_cast<f32x4*>(obase + (mrow0 + row) * a.ldo + nb + ch * 4) = v;
+                    if (live) *reinterpret_cast<f32x4*>(obase + (mrow0 + row) * a.ldo + nb + ch * 4) = v;
+                    if constexpr (FOLD == MID_FOLD_PRODUCER) {   // (NT == 2: a row's 32 columns sit in one aligned lane octet)
+                        const bf16x4 pk = {(bf16_t)(v[0] * sc4[0]), (bf16_t)(v[1] * sc4[1]), (bf16_t)(v[2] * sc4[2]), (bf16_t)(v[3] * sc4[3])};
+                        if (live) *reinterpret_cast<bf16x4*>(a.xs + (mrow0 + row) * a.ldxs + nb + ch * 4) = pk;
+                        const float s1 = mid_oct_sum((v[0] + v[1]) + (v[2] + v[3]));
+                        const float s2 = mid_oct_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                        if (live && ch == 0) *reinterpret_cast<f32x2*>(a.stats_out + ((long)(nb >> 5) * a.M + mrow0 + row) * 2) = (f32x2){s1, s2};
+                    }
                 }
             }
         };
@@ -272,29 +390,30 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <int EPI, int BN>
+template <int EPI, int BM, int BN, int FOLD = MID_FOLD_NONE>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a) {
-    using C = MidCfg<BN>;
-    constexpr int NT = C::NT;
+    using C = MidCfg<BM, BN>;
+    constexpr int NT = C::NT, MT = C::MT;
     extern __shared__ __attribute__((aligned(16))) char smem_mid[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // XCD-aware bijective remap of the 1-D tile index (blocks b, b+8, ... share an XCD's L2), column-major inside the chunk
-    const int tiles_m = (a.M + MID_BM - 1) / MID_BM, tiles_n = a.N / BN;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int tile_m = a.col_major ? wgid % tiles_m : wgid / tiles_n, tile_n = a.col_major ? wgid / tiles_m : wgid % tiles_n;
-    const int m0 = tile_m * MID_BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bool split = (EPI == EPI_F32 && a.splits > 1);
     const int ksplit = split ? a.K / a.splits : a.K;
     const int kbase = split ? (int)blockIdx.y * ksplit : 0;
     const int nkt = ksplit / MID_BK;
+    const int step = a.step_ptr ? *a.step_ptr : 0;       // device-side SDE step counter (scalar load, before any request of this kernel)
 
     if (wave >= 4) {                                     // loader waves: the operand stream, nothing else
-        mid_loader<BN>(a, smem_mid, wave - 4, lane, m0, n0, kbase, nkt);
+        mid_loader<BM, BN, FOLD>(a, smem_mid, wave - 4, lane, m0, n0, kbase, nkt, step);
         return;
     }
 
@@ -304,30 +423,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     const int sw = (lrow >> 1) & 7;
     // per-lane LDS read bases inside a stage: row * 128 + ((k-half * 4 + lchk) ^ ((row >> 1) & 7)) * 16; fragment i at + i * 2048
     const int xb0 = lrow * 128 + ((lchk ^ sw) << 4), xb1 = lrow * 128 + (((4 + lchk) ^ sw) << 4);
-    const int wrow = MID_XB + (wn * (BN / 4) + lrow) * 128;
+    const int wrow = C::XB + (wn * (BN / 4) + lrow) * 128;
     const int wb0 = wrow + ((lchk ^ sw) << 4), wb1 = wrow + (((4 + lchk) ^ sw) << 4);
 
-    f32x4 acc[NT][8];
+    f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     MID_STAMP_DECL();
     MID_STAMP(0);
-    // While the first K-tile is on its way the compute waves have nothing to do:
-    //  (1) BN = 128 residual epilogue: the wave's whole residual tile (128 rows x 32 columns fp32 = 16 x 16 B per lane) is requested now and
-    //      arrives under the main loop;
-    //  (2) W-panel touch: the tiles_m workgroups that share this W column panel (cold in HBM at every SDE step) each pull their share of its
-    //      128-B lines towards the XCD's L2 — K-tile j of the panel by the workgroup with tile_m == j mod tiles_m, one line per lane, one
-    //      dword-sized LDS-DMA per wave and K-tile into the (still unused) staging area — so the loaders' requests from K-tile 3 on are L2 hits.
-    f32x4 rpre[8][2];
-    if constexpr (EPI == EPI_RESID_F32 && NT == 2) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int it = 0; it < 2; ++it) rpre[mi][it] = mid_resid_load<NT>(a, m0, n0 + wn * (BN / 4), lane, mi, it);
-    }
+    // While the first K-tile is on its way the compute waves have nothing to do but one thing — the W-panel touch: the tiles_m workgroups that
+    // share this W column panel (cold in HBM at every SDE step) each pull their share of its 128-B lines towards the XCD's L2 — K-tile j of the
+    // panel by the workgroup with tile_m == j mod tiles_m, one line per lane, one dword-sized LDS-DMA per wave and K-tile into the (still
+    // unused) staging area.
 #ifndef MID_NO_TOUCH
     {
         const int prow = wn * 64 + lane;                 // row of the panel this lane touches (BN = 128: waves 0, 1 cover it)
@@ -335,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             const char* wl = reinterpret_cast<const char*>(a.W + (long)(n0 + prow) * a.ldw + kbase);
             char* dst = smem_mid + C::RING + wave * 4096;
             int cnt = 0;
-            for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 16; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway)
+            for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 8; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway; 8 x 256 B stay clear of the staging tails)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wl + (long)j * (MID_BK * 2)),
                                                  (__attribute__((address_space(3))) void*)(dst + cnt * 256), 4, 0, 0);
         }
@@ -343,8 +453,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
 #endif
     MID_BARRIER();                                       // prologue barrier: K-tile 0 has landed
     MID_STAMP(1);
+    // BN = 128 residual epilogue: the wave's whole residual tile (BM rows x 32 columns fp32: 2 x 16 B per lane and 16-row pass) is requested
+    // here and arrives under the main loop.  NOT before the barrier: a CU's memory pipeline is a FIFO — requested first, these
+    // 32-64 KB of (HBM / Infinity-Cache) misses held the loaders' first K-tiles back by 2-4 us (profiles/r04_mid_stamps.txt).
+    f32x4 rpre[MT][2];
+    if constexpr (EPI == EPI_RESID_F32 && NT == 2) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rpre[mi][it] = mid_resid_load<NT>(a, m0, n0 + wn * (BN / 4), lane, mi, it);
+    }
 
-    if constexpr (NT == 4) {
+    if constexpr (BM == 128 && NT == 4) {
         // K-tile = 4 blocks of 16 MFMAs: (half 0, rows 0-63), (half 0, rows 64-127), (half 1, rows 0-63), (half 1, rows 64-127);
         // each block's fragments are read during the block before it
         bf16x8 wa[4], wb[4], xa[4], xb[4];
@@ -382,7 +502,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             mid_interleave<4, 2>();
             MID_LGKM0();
             MID_BARRIER();                               // barrier kt: K-tile kt+1 landed; this stage may be refilled
-            slot = slot + 1 == MID_NS ? 0 : slot + 1;
+            slot = slot + 1 == C::NS ? 0 : slot + 1;
             st = smem_mid + slot * C::STAGE;
             ld_w(wa, st, wb0); ld_x(xa, st, xb0, 0);
             mm(wb, xb, 1);
@@ -399,8 +519,53 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
         mm(wb, xa, 0);
         mid_interleave<4, 2>();
         mm(wb, xb, 1);
+    } else if constexpr (BM == 64) {
+        // 64 x 128 tile: a wave owns 64 rows x 32 columns (2 x 4 accumulator tiles), a K-tile is ONE block of 16 MFMAs; the whole next K-tile's
+        // fragments (4 W + 8 X) are read into the other register set while this one is multiplied.  The reads of K-tile kt are complete
+        // before its MFMAs start, so the barrier that admits K-tile kt+1 also frees K-tile kt's stage.
+        bf16x8 wa[2][2], xa[2][4], wb[2][2], xb[2][4];
+        auto ld = [&](bf16x8 (&w)[2][2], bf16x8 (&x)[2][4], const char* st) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { w[0][i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048); w[1][i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[0][i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048); x[1][i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048); }
+        };
+        auto mm = [&](const bf16x8 (&w)[2][2], const bf16x8 (&x)[2][4]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[h][ni], x[h][mi], acc[ni][mi], 0, 0, 0);
+        };
+        int slot = 0;
+        auto next_stage = [&]() { slot = slot + 1 == C::NS ? 0 : slot + 1; return smem_mid + slot * C::STAGE; };
+        ld(wa, xa, smem_mid);
+        MID_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        int kt = 0;
+        for (; kt + 2 < nkt; kt += 2) {
+            MID_BARRIER();                               // barrier kt: K-tile kt+1 landed (and K-tile kt's stage is free: its reads returned before this trip)
+            ld(wb, xb, next_stage());
+            mm(wa, xa);
+            mid_interleave<12, 1>();
+            MID_LGKM0();
+            MID_BARRIER();                               // barrier kt+1
+            ld(wa, xa, next_stage());
+            mm(wb, xb);
+            mid_interleave<12, 1>();
+            MID_LGKM0();
+        }
+        if (kt + 1 < nkt) {
+            MID_BARRIER();
+            ld(wb, xb, next_stage());
+            mm(wa, xa);
+            mid_interleave<12, 1>();
+            mm(wb, xb);
+        } else mm(wa, xa);
     } else {
-        // BN = 128: a wave owns 32 columns (2 accumulator tiles x 8 row tiles); K-tile = 2 blocks of 16 MFMAs (half 0, half 1)
+        // 128 x 128: a wave owns 32 columns (2 accumulator tiles x 8 row tiles); K-tile = 2 blocks of 16 MFMAs (half 0, half 1)
         bf16x8 wa[2], wb[2], xa[8], xb[8];
         auto ld = [&](bf16x8 (&w)[2], bf16x8 (&x)[8], const char* st, int woff, int xoff) {
 #pragma unroll
@@ -426,7 +591,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             mid_interleave<10, 1>();
             MID_LGKM0();
             MID_BARRIER();
-            slot = slot + 1 == MID_NS ? 0 : slot + 1;
+            slot = slot + 1 == C::NS ? 0 : slot + 1;
             st = smem_mid + slot * C::STAGE;
             ld(wa, xa, st, wb0, xb0);
             mm(wb, xb);
@@ -440,7 +605,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     }
 
     MID_STAMP(2);
-    mid_epilogue<EPI, BN>(a, acc, m0, n0 + wn * (BN / 4), lane, smem_mid + C::RING + wave * 4096, rpre);
+    // The epilogue must not be scheduled in among the last MFMAs: left to itself hipcc starts the epilogue's LDS reads a few instructions behind
+    // MFMAs that still read the SAME registers as their C operand, and the returned data then overwrites an operand in flight — measured: the
+    // LN-folded consumer lost the mean term in some lanes of the first 16-row pass, differently from run to run (tools/dbg/mid_fold_dbg.py;
+    // profiles/r04_mid_epilogue_hazard.txt).  A scheduling fence + the matrix pipe's depth in wait states; once per kernel.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mid_epilogue<EPI, BM, BN, FOLD>(a, acc, m0, n0 + wn * (BN / 4), wn, lane, smem_mid + C::RING + wave * 4096, smem_mid + C::RING, rpre, step);
 #ifdef MID_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MID_STAMP(3);
@@ -449,47 +621,57 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------- launcher
-// Shapes this kernel takes (everything else stays with gemm_bf16.hip): whole column tiles, 16-byte aligned rows, K a multiple of 64.
+// Shapes this kernel takes (everything else stays with gemm_bf16.hip): whole column tiles, 16-byte aligned rows, K a multiple of 64,
+// and a problem of at most two rounds of workgroups (longer ones belong to the persistent 256^2 kernel or the streaming v1 forms).
 static int mid_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("LDT_GEMM_MID"); v = e ? atoi(e) : 1; }
     return v;
 }
 
-// tile width for (M, N): 256 when that still gives most CUs a tile, else 128; 0 = not a mid-size problem
-int ldt_gemm_mid_bn(int epi, const GemmArgs* a) {
-    if (!mid_env()) return 0;
+// Tile shape for (M, N): this path is bound by what a CU can take in through the L2 -> LDS DMA (~80 GB/s, profiles/r04_mid_stamps.txt), so
+// the cost of a shape is rounds x bytes per workgroup and K-tile ~ ceil(workgroups / 256) x (BM + BN).  -> (BM << 16) | BN, 0 = not taken.
+int ldt_gemm_mid_shape(int epi, const GemmArgs* a) {
+    const int mode = mid_env();                          // 0 off, 1 automatic; tools/dbg: 256 / 128 / 64 pin 128x256 / 128x128 / 64x128
+    if (!mode) return 0;
     if (!(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32)) return 0;
-    if (a->K % MID_BK != 0 || a->N % 128 != 0 || a->M < 128 || a->ldo % 8 != 0) return 0;
+    if (a->K % MID_BK != 0 || a->N % 128 != 0 || a->M < 64 || a->ldo % 8 != 0) return 0;
     if (a->splits > 1 && (epi != EPI_F32 || a->K % (a->splits * MID_BK) != 0)) return 0;
     if (epi == EPI_RESID_F32 && (a->ldr % 4 != 0 || (a->gate && a->gate_sample_stride % 4 != 0))) return 0;
-    const int sp = a->splits > 1 ? a->splits : 1;
-    const long tm = (a->M + MID_BM - 1) / MID_BM;
-    const long t256 = (a->N % 256 == 0) ? tm * (a->N / 256) * sp : 0, t128 = tm * (a->N / 128) * sp;
-    const int forced = mid_env();                        // LDT_GEMM_MID=256 / 128 pins the width (tools/dbg)
-    if (forced == 256) return t256 ? 256 : 0;
-    if (forced == 128) return 128;
-    if (t256 * 8 >= LDT_NUM_CUS * 5) return 256;         // >= 160 workgroups of the wide tile
-    if (t128 * 8 >= LDT_NUM_CUS * 3) return 128;         // >= 96 of the narrow one
-    return 0;
+    const long sp = a->splits > 1 ? a->splits : 1;
+    struct { int bm, bn; } cand[3] = {{128, 256}, {128, 128}, {64, 128}};
+    if (mode == 256) return a->N % 256 == 0 ? (128 << 16) | 256 : 0;
+    if (mode == 128) return (128 << 16) | 128;
+    if (mode == 64) return (64 << 16) | 128;
+    long best_cost = 0; int best = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (a->N % cand[i].bn != 0) continue;
+        const long wgs = (long)((a->M + cand[i].bm - 1) / cand[i].bm) * (a->N / cand[i].bn) * sp;
+        if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) continue;
+        const long cost = ((wgs + LDT_NUM_CUS - 1) / LDT_NUM_CUS) * (cand[i].bm + cand[i].bn);
+        if (!best || cost < best_cost) { best = (cand[i].bm << 16) | cand[i].bn; best_cost = cost; }
+    }
+    return best;
 }
 
-template <int EPI, int BN>
+template <int EPI, int BM, int BN>
 static int mid_launch_t(const GemmArgs* a_in, hipStream_t stream) {
-    using C = MidCfg<BN>;
+    using C = MidCfg<BM, BN>;
     GemmArgs a = *a_in;
-    const long tm = (a.M + MID_BM - 1) / MID_BM, tn = a.N / BN;
+    const long tm = (a.M + BM - 1) / BM, tn = a.N / BN;
     static const int map_env = getenv("LDT_GEMM_MID_MAP") ? atoi(getenv("LDT_GEMM_MID_MAP")) : -1;   // tools/dbg: 0 row-major, 1 column-major
     a.col_major = map_env >= 0 ? map_env : 1;
-    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI, BN>), C::LDS, "gemm_mid");
+    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI, BM, BN>), C::LDS, "gemm_mid");
     const unsigned sp = (EPI == EPI_F32 && a.splits > 1) ? (unsigned)a.splits : 1u;
-    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI, BN>), dim3((unsigned)(tm * tn), sp), dim3(512), C::LDS, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI, BM, BN>), dim3((unsigned)(tm * tn), sp), dim3(512), C::LDS, stream, a);
     return ldt_check_launch("gemm_bf16_nt_mid");
 }
 
-int ldt_gemm_mid_launch(int epi, int bn, const GemmArgs* a, hipStream_t stream) {
-#define MID_CASE(E)                                                                  \
-    case E: return bn == 256 ? mid_launch_t<E, 256>(a, stream) : mid_launch_t<E, 128>(a, stream)
+int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream) {
+    const int bm = shape >> 16, bn = shape & 0xffff;
+#define MID_CASE(E)                                                                                            \
+    case E: return bm == 64 ? mid_launch_t<E, 64, 128>(a, stream) : bn == 256 ? mid_launch_t<E, 128, 256>(a, stream) \
+                                                                               : mid_launch_t<E, 128, 128>(a, stream)
     switch (epi) {
         MID_CASE(EPI_F32);
         MID_CASE(EPI_BF16);
@@ -498,4 +680,40 @@ int ldt_gemm_mid_launch(int epi, int bn, const GemmArgs* a, hipStream_t stream) 
         default: ldt_set_error("gemm_mid: epilogue %d not built", epi); return LDT_EARG;
     }
 #undef MID_CASE
+}
+
+// LN-folded forms (ldt_gemm_lnfold_launch's small-batch route: statistics per 32 columns): producer = the N = hidden residual GEMMs on
+// 64 x 128 / 128 x 128 tiles, consumer = QKV / MLP-up on 128 x 256 / 128 x 128 tiles.  -> true when this kernel took the launch.
+template <int EPI, int BM, int BN, int FOLD>
+static int mid_fold_launch_t(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = MidCfg<BM, BN>::LDS;
+    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI, BM, BN, FOLD>), lds, "gemm_mid(fold)");
+    const unsigned grid = (unsigned)(((a.M + BM - 1) / BM) * (a.N / BN));
+    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI, BM, BN, FOLD>), dim3(grid), dim3(512), lds, stream, a);
+    return ldt_check_launch("gemm_bf16_nt_mid(fold)");
+}
+
+bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a_in, hipStream_t stream, int* status) {
+    if (!mid_env()) return false;
+    const int shape = ldt_gemm_mid_shape(epi, a_in);
+    if (!shape) return false;
+    const int bm = shape >> 16, bn = shape & 0xffff;
+    GemmArgs a = *a_in;
+    static const int map_env = getenv("LDT_GEMM_MID_MAP") ? atoi(getenv("LDT_GEMM_MID_MAP")) : -1;
+    a.col_major = map_env >= 0 ? map_env : 1;
+    if (epi == EPI_RESID_F32) {                          // producer: a wave's 32 columns are the statistics granule
+        if (bn != 128 || a.stats_parts * 32 != a.N) return false;
+        *status = bm == 64 ? mid_fold_launch_t<EPI_RESID_F32, 64, 128, MID_FOLD_PRODUCER>(a, stream)
+                           : mid_fold_launch_t<EPI_RESID_F32, 128, 128, MID_FOLD_PRODUCER>(a, stream);
+        return true;
+    }
+    // consumer: the loader waves' statistics pass assumes the whole ring is in flight and <= 32 partials per row
+    if (bm != 128 || a.stats_parts > 32 || a.stats_parts * 32 != a.K || a.K / MID_BK < MidCfg<128, 256>::NS + 2) return false;
+    if (epi == EPI_BF16)
+        *status = bn == 256 ? mid_fold_launch_t<EPI_BF16, 128, 256, MID_FOLD_CONSUMER>(a, stream) : mid_fold_launch_t<EPI_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
+    else if (epi == EPI_GELU_BF16)
+        *status = bn == 256 ? mid_fold_launch_t<EPI_GELU_BF16, 128, 256, MID_FOLD_CONSUMER>(a, stream)
+                            : mid_fold_launch_t<EPI_GELU_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
+    else return false;
+    return true;
 }

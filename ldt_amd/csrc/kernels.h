@@ -76,8 +76,9 @@ struct SgemmArgs {
 };
 
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
-int ldt_gemm_mid_bn(int epi, const GemmArgs* a);                   // gemm_mid.hip: tile width (256 / 128) the mid-size kernel would use, 0 = not taken
-int ldt_gemm_mid_launch(int epi, int bn, const GemmArgs* a, hipStream_t stream);
+int ldt_gemm_mid_shape(int epi, const GemmArgs* a);                // gemm_mid.hip: (BM << 16) | BN of the mid-size tile kernel for this problem, 0 = not taken
+int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream);
+bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
 bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // every GEMM of a Score block on the v1 kernels: statistics per 32 columns
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);

@@ -71,9 +71,11 @@ def test_gemm_all_epilogues(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 4096, 1024), (2048, 3072, 1024), (2048, 1024, 4096), (1024, 4096, 1024), (1024, 1024, 1024),
                                    (2048, 4096, 64), (2048, 4096, 128), (2048, 4096, 192), (1152, 1536, 64), (1152, 1536, 192),
-                                   (1000, 2304, 320), (1960, 4096, 320), (4096, 1024, 1024)])
+                                   (1000, 2304, 320), (1960, 4096, 320), (4096, 1024, 1024),
+                                   # 64 x 128 tiles (4-stage ring, K-tile-deep register double buffering): 1..5 K-tiles, ragged rows
+                                   (2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (2048, 1024, 320), (1000, 1024, 448)])
 def test_gemm_mid_kernel(M, N, K):
-    """The mid-size tile kernel (csrc/gemm_mid.hip: 128 x 256 / 128 x 128 tiles, loader waves, 3-stage ring) on the shapes the launcher hands
+    """The mid-size tile kernel (csrc/gemm_mid.hip: 128 x 256 / 128 x 128 / 64 x 128 tiles, loader waves, 3- / 4-stage ring) on the shapes the launcher hands
     it — incl. 1 / 2 / 3 / 5 K-tiles (prologue and drain paths of the ring), a ragged last row tile, a step-indexed shared gate, a per-sample
     gate and split-K partials — vs fp64 on the same bf16 operands."""
     from ldt_amd._lib import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32

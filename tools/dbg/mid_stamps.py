@@ -11,7 +11,7 @@ L.ldt_dbg_mid_stamps.argtypes = [ctypes.c_void_p]
 torch.manual_seed(0)
 cold = torch.empty(256 * 1024 * 1024, device="cuda", dtype=torch.float32)
 for (name, M, N, K, epi, flush) in [("up", 2048, 4096, 1024, EPI_GELU_BF16, False), ("up", 2048, 4096, 1024, EPI_GELU_BF16, True),
-                                    ("qkv", 2048, 3072, 1024, EPI_BF16, True), ("dn", 2048, 1024, 4096, EPI_RESID_F32, True),
+                                    ("qkv", 2048, 3072, 1024, EPI_BF16, True), ("dn", 2048, 1024, 4096, EPI_RESID_F32, True), ("dn", 2048, 1024, 4096, EPI_RESID_F32, False), ("o", 2048, 1024, 1024, EPI_RESID_F32, True),
                                     ("up1k", 1024, 4096, 1024, EPI_GELU_BF16, True)]:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     b = torch.randn(N, device="cuda")
