@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 16
+#define LDT_ABI_VERSION 17
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -91,20 +91,6 @@ int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy
                            int64_t mod_sample_stride, int32_t rows_per_sample,
                            const int32_t* step_ptr, int64_t mod_step_stride,
                            int64_t M, int32_t C, void* stream);
-
-/* ---- small-batch regime: split-K residual GEMM + the residual add folded into the LayerNorm -------------------------
- * ldt_gemm_bf16_splitk: parts[s][M][N] fp32 = X[:, s K/splits : (s+1) K/splits] . W[:, same]^T  (raw partial products, no bias),
- *   s = 0 .. splits-1 (<= 16), K % (splits * 64) == 0.  For fc_o / mlp.out (model/layers.py:218-219) when M*N gives too few
- *   output tiles to fill the chip (T = 32 latents: M = 1-2k rows).
- * ldt_layernorm_modulate_resid: x[m,:] <- x[m,:] + gate[s,:] * (sum_s parts[s][m,:] + bias)   (in place, fp32; gate NULL = 1),
- *   then y = LN(x)(1 + scale) + shift as ldt_layernorm_modulate.  gate / shift / scale share the (step, sample) addressing.
- *   The partial sums are added in the order s = 0, 1, ...: results are bit-reproducible. */
-int ldt_gemm_bf16_splitk(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, float* parts, int32_t splits,
-                         int32_t M, int32_t N, int32_t K, void* stream);
-int ldt_layernorm_modulate_resid(float* x, uint16_t* y, int64_t ldy, const float* parts, int32_t nparts, const float* bias,
-                                 const float* gate, const float* shift, const float* scale, int64_t mod_sample_stride,
-                                 int32_t rows_per_sample, const int32_t* step_ptr, int64_t mod_step_stride, int64_t M, int32_t C,
-                                 void* stream);
 
 /* ---- fused multi-head attention ---------------------------------------------------------------------
  * O[b,h,n,:] = softmax(Q K^T / sqrt(Dh)) V, heads at channel offset h*Dh of each row; output is the
@@ -327,11 +313,6 @@ typedef struct ldt_score_plan {
        the folded projections' rounding error, (1 + mean^2 / variance) x the LayerNorm kernel's.  The sampler sets it on a
        probe forward before and after the loop (ldt_amd/diffusion.py) and leaves it NULL inside the loop. */
     float* fold_monitor;
-    /* Optional split-K workspace for the small-batch regime (NULL = off): fp32 [splitk_parts][batch*tokens][hidden].  When set and
-       the residual GEMMs (fc_o, mlp.out: N = hidden) have too few output tiles to fill the chip, they run split over K into this
-       buffer and the LayerNorm that follows performs x <- x + gate * (sum of partials + bias) before normalising (fixed summation
-       order: deterministic).  Ignored where LN folding is active. */
-    float* splitk_ws; int32_t splitk_parts; int32_t _pad2;
 } ldt_score_plan;
 
 /* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */

@@ -91,24 +91,6 @@ extern "C" int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, 
     return ldt_ln_launch(&a, ST(stream));
 }
 
-extern "C" int ldt_gemm_bf16_splitk(const uint16_t* X, int64_t ldx, const uint16_t* W, int64_t ldw, float* parts, int32_t splits,
-                                    int32_t M, int32_t N, int32_t K, void* stream) {
-    LDT_REQUIRE(X && W && parts && splits >= 1, LDT_EARG, "gemm_splitk: null pointer / splits");
-    GemmArgs a{BF(X), ldx, BF(W), ldw, nullptr, parts, N, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, N, K};
-    a.splits = splits; a.split_stride = (long)M * N;
-    return ldt_gemm_launch(EPI_F32, &a, ST(stream));
-}
-
-extern "C" int ldt_layernorm_modulate_resid(float* x, uint16_t* y, int64_t ldy, const float* parts, int32_t nparts, const float* bias,
-                                            const float* gate, const float* shift, const float* scale, int64_t mod_sample_stride,
-                                            int32_t rows_per_sample, const int32_t* step_ptr, int64_t mod_step_stride, int64_t M, int32_t C,
-                                            void* stream) {
-    LDT_REQUIRE(x && y && parts && nparts >= 1, LDT_EARG, "ln_resid: null pointer / nparts");
-    LnArgs a{x, C, BFM(y), ldy, nullptr, nullptr, shift, scale, mod_sample_stride, rows_per_sample, step_ptr, mod_step_stride, M, C};
-    a.part = parts; a.nparts = nparts; a.part_stride = (long)M * C; a.pbias = bias; a.gate = gate; a.x_out = x;
-    return ldt_ln_launch(&a, ST(stream));
-}
-
 extern "C" int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride, const uint16_t* K,
                                  int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride, uint16_t* O,
                                  int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream) {
@@ -304,27 +286,6 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     for (int l = 0; l < p->blocks && fold; ++l) fold = !p->kv_cond[l];
     const int sparts = fold_v1 ? D / 32 : D / 256;              // row-statistics partials per row in plan->stats ([sparts][M][2])
     const long fstep = p->fold_step_stride, fblk = 6L * D + 2L * F;   // per block: S_qkv[3D] | C_qkv[3D] | S_up[F] | C_up[F]
-    // Split-K for the residual GEMMs of a small batch (include/ldt_hip.h, ldt_score_plan.splitk_ws) — OPT-IN (LDT_SPLITK=1, or =n to
-    // force n splits).  With N = hidden = 1024 a 1-2k-row batch has 32-128 output tiles of 128^2 for 256 CUs, and smaller tiles stream
-    // 2-4x the operand bytes through the L2 -> LDS path; cutting K makes ~512 workgroups of 128^2 and moves the residual add into the
-    // LayerNorm kernel that follows (ln_resid_row_kernel).  Measured (round 3, tools/dbg/splitk_bench.py, profiles/r03_t32_*): the
-    // 2-phase 128^2 kernel is bound per workgroup (~0.65 PFLOP/s chip-wide at every tile count), so mlp.out at M = 2048 only goes
-    // 30 -> 26.5 us while the reducing LayerNorm costs +5-10 us: no net gain — kept for the parity tests and as the seam for a faster
-    // mid-size tile kernel.
-    static const int sk_env = getenv("LDT_SPLITK") ? atoi(getenv("LDT_SPLITK")) : 0;    // 0 off (default); 1 automatic; n > 1 forces n splits
-    const long tiles128 = (long)((M + 127) / 128) * ((D + 127) / 128);
-    int sk_o = 1, sk_d = 1;
-    if (!fold && p->splitk_ws && p->splitk_parts >= 2 && sk_env > 0 && D % 256 == 0 && D <= 1024 && (tiles128 < 2 * LDT_NUM_CUS || sk_env > 1)) {
-        auto pick = [&](int K) {
-            int want = sk_env > 1 ? sk_env : (int)((2 * LDT_NUM_CUS + tiles128 - 1) / tiles128);
-            if (want > p->splitk_parts) want = p->splitk_parts;
-            while (want > 1 && (K % (want * 64) != 0 || K / want < 256)) --want;
-            return want < 1 ? 1 : want;
-        };
-        sk_o = pick(D); sk_d = pick(F);
-    }
-    const long sk_stride = (long)M * D;
-    struct { const float* bias; const float* gate; int parts; } pend{nullptr, nullptr, 0};   // mlp.out partials awaiting the next LayerNorm
     // ln_in (score.py:136-137): latents fp32 -> bf16 (K padded) -> X fp32
     LAUNCH(LDT_PROF_OTHER, ldt_cast_pad_launch(x, p->z_dim, BFM(p->xin), p->z_pad, M, p->z_dim, p->z_pad, s));
     {
@@ -343,7 +304,6 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
         } else {
         LnArgs n1{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
-        if (pend.parts) { n1.part = p->splitk_ws; n1.nparts = pend.parts; n1.part_stride = sk_stride; n1.pbias = pend.bias; n1.gate = pend.gate; n1.x_out = p->X; pend.parts = 0; }
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n1, s));
         if (p->kv_cond[l]) {                                    // cross-attention: q from the modulated x, K|V from the condition
             const int S = p->cond_tokens;
@@ -380,24 +340,14 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             continue;
         }
         LnArgs n2{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m + 3 * D, m + 4 * D, sstr, T, step_ptr, tstr, M, D};
-        if (sk_o > 1) {                                          // fc_o as raw split-K partials; gate * (sum + bias) + x happens in n2
-            GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, nullptr, p->splitk_ws, D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, D};
-            go.splits = sk_o; go.split_stride = sk_stride;
-            LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_launch(LDT_EPI_F32, &go, s));
-            n2.part = p->splitk_ws; n2.nparts = sk_o; n2.part_stride = sk_stride; n2.pbias = p->b_o[l]; n2.gate = m + 2 * D; n2.x_out = p->X;
-        } else {
+        {
             GemmArgs go{BF(p->Ob), D, BF(p->w_o[l]), D, p->b_o[l], p->X, D, p->X, D, nullptr, 0, m + 2 * D, sstr, T, step_ptr, tstr, M, D, D};
             go.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_O, ldt_gemm_launch(LDT_EPI_RESID_F32, &go, s));
         }
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n2, s));
         GemmArgs gu{BF(p->Hb), D, BF(p->w_up[l]), D, p->b_up[l], p->U, F, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, F, D};
         gu.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_GELU, ldt_gemm_launch(LDT_EPI_GELU_BF16, &gu, s));
-        if (sk_d > 1) {                                          // mlp.out as split-K partials, reduced by the NEXT LayerNorm (block l+1's, or the FinalLayer's)
-            GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, nullptr, p->splitk_ws, D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, F};
-            gd.splits = sk_d; gd.split_stride = sk_stride;
-            LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_F32, &gd, s));
-            pend.bias = p->b_dn[l]; pend.gate = m + 5 * D; pend.parts = sk_d;
-        } else {
+        {
             GemmArgs gd{BF(p->U), F, BF(p->w_dn[l]), F, p->b_dn[l], p->X, D, p->X, D, nullptr, 0, m + 5 * D, sstr, T, step_ptr, tstr, M, D, F};
             gd.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_DN, ldt_gemm_launch(LDT_EPI_RESID_F32, &gd, s));
         }
@@ -405,7 +355,6 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
     {                                                           // FinalLayer (layers.py:240-248)
         const float* m = p->mod + (long)p->blocks * 6 * D;
         LnArgs nf{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
-        if (pend.parts) { nf.part = p->splitk_ws; nf.nparts = pend.parts; nf.part_stride = sk_stride; nf.pbias = pend.bias; nf.gate = pend.gate; nf.x_out = p->X; pend.parts = 0; }
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&nf, s));
         GemmArgs gf{BF(p->Hb), D, BF(p->w_out), D, p->b_out, eps_out, p->z_dim, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, p->z_dim, D};
         gf.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_IO, ldt_gemm_launch(LDT_EPI_F32, &gf, s));

@@ -39,39 +39,19 @@ int ldt_cast_pad_launch(const float* src, long lds, bf16_t* dst, long ldd, long 
 //   reference: tools/utils.py:127-133 (LayerNorm wrapper), model/layers.py:136-137 (modulate), :218-219 (use)
 // One wave per row; shift/scale are per-sample vectors (stride 0 = shared by the batch, the
 // unconditional sampler's case: SURVEY hard part 3) selected by a device-side step counter.
-template <int NV, bool RESID = false>   // NV float4 chunks per lane: C = NV*256; RESID: residual + split-K reduction first (LnArgs.part)
+template <int NV>   // NV float4 chunks per lane: C = NV*256
 __global__ __launch_bounds__(256) void ln_mod_vec_kernel(const LnArgs a) {
     const int lane = threadIdx.x & 63;
     const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const float* xr = a.x + row * a.ldx;
-    const long modoff = (a.shift || a.part) ? (a.step_ptr ? (long)(*a.step_ptr) * a.mod_step_stride : 0) + (row / a.rows_per_sample) * a.mod_sample_stride : 0;
+    const long modoff = a.shift ? (a.step_ptr ? (long)(*a.step_ptr) * a.mod_step_stride : 0) + (row / a.rows_per_sample) * a.mod_sample_stride : 0;
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-        if (RESID) {
-            // x <- x + gate * (sum_s part[s] + bias): the residual update of layers.py:218-219 with the split-K partials of the GEMM that
-            // precedes this LayerNorm summed in the fixed order s = 0, 1, ... (deterministic), written back in place
-            f32x4 acc = *reinterpret_cast<const f32x4*>(a.part + row * (long)a.C + c);
-            for (int sp = 1; sp < a.nparts; ++sp) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(a.part + sp * a.part_stride + row * (long)a.C + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += t[j];
-            }
-            if (a.pbias) { const f32x4 b = *reinterpret_cast<const f32x4*>(a.pbias + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += b[j]; }
-            if (a.gate) { const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + modoff + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] = v[i][j] + g[j] * acc[j]; }
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[i][j] = v[i][j] + acc[j]; }
-            *reinterpret_cast<f32x4*>(a.x_out + row * a.ldx + c) = v[i];
-        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)a.C;
@@ -99,60 +79,6 @@ __global__ __launch_bounds__(256) void ln_mod_vec_kernel(const LnArgs a) {
         bf16x4 pk = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
         *reinterpret_cast<bf16x4*>(yr + c) = pk;
     }
-}
-
-// Residual + split-K reduction + LayerNorm with ONE WORKGROUP PER ROW (C / 4 threads, C = 256 .. 1024): the small-batch regime
-// has only 1-4k rows, and a wave per row (above) leaves the CUs at 8 waves with 20 dependent-latency loads each; here every thread
-// owns one float4 of the row (x + nparts partials), the two row reductions go through LDS (fixed order: deterministic).
-__global__ __launch_bounds__(256) void ln_resid_row_kernel(const LnArgs a) {
-    const long row = blockIdx.x;
-    const int tid = threadIdx.x, c = tid * 4;
-    const int nw = blockDim.x >> 6;
-    const long modoff = (a.step_ptr ? (long)(*a.step_ptr) * a.mod_step_stride : 0) + (row / a.rows_per_sample) * a.mod_sample_stride;
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + c);
-    f32x4 acc = *reinterpret_cast<const f32x4*>(a.part + row * (long)a.C + c);
-    for (int sp = 1; sp < a.nparts; ++sp) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(a.part + sp * a.part_stride + row * (long)a.C + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += t[j];
-    }
-    if (a.pbias) { const f32x4 b = *reinterpret_cast<const f32x4*>(a.pbias + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += b[j]; }
-    if (a.gate) { const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + modoff + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] + g[j] * acc[j]; }
-    else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] + acc[j]; }
-    *reinterpret_cast<f32x4*>(a.x_out + row * a.ldx + c) = v;
-    __shared__ float red[2][4];
-    const float s = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
-    if ((tid & 63) == 0) red[0][tid >> 6] = s;
-    __syncthreads();
-    float tot = red[0][0];
-    for (int w = 1; w < nw; ++w) tot += red[0][w];
-    const float mean = tot / (float)a.C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; q += d * d; }
-    q = wave_sum(q);
-    if ((tid & 63) == 0) red[1][tid >> 6] = q;
-    __syncthreads();
-    float qt = red[1][0];
-    for (int w = 1; w < nw; ++w) qt += red[1][w];
-    const float rstd = rsqrtf(qt / (float)a.C + 1e-6f);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd;
-    if (a.w) { const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.w + c); const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = o[j] * w4[j] + b4[j]; }
-    if (a.shift) { const f32x4 h = *reinterpret_cast<const f32x4*>(a.shift + modoff + c); const f32x4 g = *reinterpret_cast<const f32x4*>(a.scale + modoff + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = o[j] * (1.f + g[j]) + h[j]; }
-    const bf16x4 pk = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-    *reinterpret_cast<bf16x4*>(a.y + row * a.ldy + c) = pk;
 }
 
 // generic C (any width): three passes over the (cache-resident) row
@@ -191,23 +117,6 @@ int ldt_ln_launch(const LnArgs* a, hipStream_t s) {
     const bool vec = (a->C % 256 == 0) && a->C <= 1024 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && ldt_aligned16(a->x) &&
                      (reinterpret_cast<uintptr_t>(a->y) & 7) == 0 && (!a->shift || (ldt_aligned16(a->shift) && ldt_aligned16(a->scale) &&
                      a->mod_sample_stride % 4 == 0 && a->mod_step_stride % 4 == 0)) && (!a->w || (ldt_aligned16(a->w) && ldt_aligned16(a->b)));
-    if (a->part) {
-        LDT_REQUIRE(vec && a->nparts >= 1 && a->x_out && a->ldx == a->C && a->rows_per_sample > 0 && ldt_aligned16(a->part) && a->part_stride % 4 == 0 &&
-                    (!a->pbias || ldt_aligned16(a->pbias)) && (!a->gate || ldt_aligned16(a->gate)), LDT_EARG,
-                    "ln: the residual / split-K form needs the vector path (C %% 256 == 0 <= 1024, dense rows) and aligned operands");
-        static const int row_form = getenv("LDT_LN_RESID_ROW") ? atoi(getenv("LDT_LN_RESID_ROW")) : 1;   // 0: the wave-per-row form (tools/dbg A/B)
-        if (row_form && a->M <= 16384) {
-            hipLaunchKernelGGL(ln_resid_row_kernel, dim3((unsigned)a->M), dim3((unsigned)(a->C / 4)), 0, s, *a);
-            return ldt_check_launch("ln_modulate(resid, row)");
-        }
-        switch (a->C / 256) {
-            case 1: hipLaunchKernelGGL((ln_mod_vec_kernel<1, true>), grid, block, 0, s, *a); break;
-            case 2: hipLaunchKernelGGL((ln_mod_vec_kernel<2, true>), grid, block, 0, s, *a); break;
-            case 3: hipLaunchKernelGGL((ln_mod_vec_kernel<3, true>), grid, block, 0, s, *a); break;
-            default: hipLaunchKernelGGL((ln_mod_vec_kernel<4, true>), grid, block, 0, s, *a); break;
-        }
-        return ldt_check_launch("ln_modulate(resid)");
-    }
     if (vec) {
         switch (a->C / 256) {
             case 1: hipLaunchKernelGGL(ln_mod_vec_kernel<1>, grid, block, 0, s, *a); break;

@@ -97,12 +97,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // split-K (EPI_F32, launcher): blockIdx.y = split s takes k in [s Ks, (s+1) Ks) and writes its own fp32 partial tile
-    const int ksplit = (EPI == EPI_F32 && a.splits > 1) ? a.K / a.splits : a.K;
-    const int kbase = (EPI == EPI_F32 && a.splits > 1) ? (int)blockIdx.y * ksplit : 0;
-    const bf16_t* Xk = a.X + kbase;
-    const bf16_t* Wk = a.W + kbase;
-    const int nk = ksplit / BK;
+    const bf16_t* Xk = a.X;
+    const bf16_t* Wk = a.W;
+    const int nk = a.K / BK;
     stage_tile<TBM, NW>(Xk, a.ldx, m0, a.M, 0, smem, wave, lane);
     stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, 0, smem + XB, wave, lane);
     // stages 1 .. NST-2 follow at once; wait until only they are outstanding (stage 0 landed)
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                 for (int r = 0; r < 4; ++r) v[r] += b[r];
             }
             if (EPI == EPI_F32) {
-                float* o = reinterpret_cast<float*>(a.out) + (a.splits > 1 ? (long)blockIdx.y * a.split_stride : 0L) + (long)m * a.ldo + n;
+                float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
                 if (full) *reinterpret_cast<f32x4*>(o) = v;
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = v[r];
             } else if (EPI == EPI_RESID_F32) {
@@ -1276,32 +1273,15 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     }
     LDT_REQUIRE(!a->bias || ldt_aligned16(a->bias), LDT_EALIGN, "gemm: bias must be 16-byte aligned");
     if (gemm_variant() == 0) {
-        // mid-size problems (gemm_mid.hip): 128 x 256 / 128 x 128 tiles with dedicated loader waves, when the 256^2 persistent kernel would
-        // leave CUs idle (its 5/8 rule below) — the 1-4k-row batches; also their split-K partials
+        // mid-size problems (gemm_mid.hip): 128 x 256 / 128 x 192 / 128 x 128 / 64 x 128 tiles with dedicated loader waves, when the 256^2
+        // persistent kernel would leave CUs idle (its 5/8 rule below) — the 1-4k-row batches
         const int t256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
         const int lim = (a->max_wgs > 0 && a->max_wgs < LDT_NUM_CUS) ? a->max_wgs : LDT_NUM_CUS;
-        const bool big = t256 * 8 >= lim * 5 && a->N > 128 && a->splits <= 1;
+        const bool big = t256 * 8 >= lim * 5 && a->N > 128;
         if (!big) {
             const int shape = ldt_gemm_mid_shape(epi, a);
             if (shape) return ldt_gemm_mid_launch(epi, shape, a, stream);
         }
-    }
-    if (a->splits > 1) {
-        // split-K (small-M regime: the residual GEMMs of a 1-2k-row batch have too few output tiles to fill 256 CUs with a tile large
-        // enough to keep the operand stream under the L2 -> LDS rate): fp32 partial tiles, reduced by the consumer (ldt_ln_launch)
-        LDT_REQUIRE(epi == EPI_F32 && !a->bias, LDT_EARG, "gemm: split-K writes raw fp32 partials (EPI_F32, no bias)");
-        LDT_REQUIRE(a->splits <= 16 && a->K % (a->splits * BK) == 0 && a->split_stride >= (long)a->M * a->ldo, LDT_ESHAPE,
-                    "gemm: split-K needs K=%d a multiple of splits*%d and split_stride >= M*ldo", a->K, BK);
-        auto nt = [&](int bm, int bn) { return (long)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
-        static const int sk_shape = getenv("LDT_GEMM_SPLITK_SHAPE") ? atoi(getenv("LDT_GEMM_SPLITK_SHAPE")) : -1;   // tools/dbg
-        const int shape = sk_shape >= 0 ? sk_shape : (nt(128, 128) * a->splits >= 2 * LDT_NUM_CUS) ? 0 : (nt(128, 64) * a->splits >= 2 * LDT_NUM_CUS ? 1 : 2);
-        dim3 block(256);
-        if (shape == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 256, 128, 3, 8>), dim3((unsigned)nt(256, 128), (unsigned)a->splits), dim3(512), 0, stream, *a);
-        else if (shape == 4) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128, 4, 8>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), dim3(512), 0, stream, *a);
-        else if (shape == 0) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 128>), dim3((unsigned)nt(128, 128), (unsigned)a->splits), block, 0, stream, *a);
-        else if (shape == 1) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 128, 64>), dim3((unsigned)nt(128, 64), (unsigned)a->splits), block, 0, stream, *a);
-        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI_F32, 64, 64, 3>), dim3((unsigned)nt(64, 64), (unsigned)a->splits), block, 0, stream, *a);
-        return ldt_check_launch("gemm_bf16_nt(split-K)");
     }
     const int tiles256 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     const int force = gemm_variant();

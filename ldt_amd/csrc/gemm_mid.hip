@@ -27,7 +27,7 @@
 //   * LDS: 3 x (X[128][64] | W[BN][64]) bf16 with 128-B rows, 16-B chunk index XORed with (row >> 1) & 7 on the DMA source address and
 //     on the ds_read address (conflict-free ds_read_b128) + 4 KiB of staging per compute wave: 160 KiB at BN = 256, 112 KiB at BN = 128.
 //   * epilogues through the per-wave staging area so that every global access is 16 B per lane over whole rows:
-//     EPI_F32 (also split-K partials: blockIdx.y = K slice), EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32 (gate per step and/or per sample).
+//     EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32 (gate per step and/or per sample), and the LN-folded producer / consumer forms.
 //   * tile order: XCD-aware bijective remap; column-major inside an XCD's chunk (an XCD reads its own slice of W — cold in HBM every
 //     step — exactly once, and shares the small X panel set through L2 / Infinity Cache).
 #include <stdlib.h>
@@ -38,12 +38,13 @@
 
 #define MID_BK 64
 
-// BM x BN output tile: 128 x 256 (the widest a CU's LDS and the accumulator budget take), 128 x 128, and 64 x 128 for the N = hidden
-// residual GEMMs of a 2k-row batch (256 workgroups instead of 128; the smaller stage buys a 4-deep ring)
+// BM x BN output tile: 128 x 256 (the widest a CU's LDS and the accumulator budget take), 128 x 192 (bf16-output epilogues only: QKV with
+// N = 3 x 1024 over 2k rows is exactly 256 such tiles), 128 x 128, and 64 x 128 for the N = hidden residual GEMMs of a 2k-row batch
+// (256 workgroups instead of 128; the smaller stage buys a 4-deep ring)
 template <int BM, int BN>
 struct MidCfg {
     static constexpr int MT = BM / 16;                   // 16-row accumulator tiles per compute wave (a wave spans all BM rows)
-    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (a wave = BN / 4 columns)
+    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (a wave = BN / 4 columns: 4 | 3 | 2 tiles)
     static constexpr int XB = BM * MID_BK * 2;           // X part of a stage (bytes)
     static constexpr int STAGE = XB + BN * MID_BK * 2;
     static constexpr int NS = BM == 64 ? 4 : 3;          // ring stages
@@ -100,7 +101,7 @@ __device__ long long* g_mid_stamps;
 extern "C" int ldt_dbg_mid_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_stamps), &p, sizeof(p)); }
 #define MID_STAMP_DECL() long long _stv = 0
 #define MID_STAMP(idx) do { const long long _t = __builtin_amdgcn_s_memrealtime(); _stv = (lane == (idx)) ? _t : _stv; } while (0)
-#define MID_STAMP_FLUSH(role) do { if (g_mid_stamps) g_mid_stamps[((long)(blockIdx.x + blockIdx.y * gridDim.x) * 2 + (role)) * 64 + lane] = _stv; } while (0)
+#define MID_STAMP_FLUSH(role) do { if (g_mid_stamps) g_mid_stamps[((long)blockIdx.x * 2 + (role)) * 64 + lane] = _stv; } while (0)
 #else
 #define MID_STAMP_DECL()
 #define MID_STAMP(idx)
@@ -111,44 +112,43 @@ extern "C" int ldt_dbg_mid_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 template <int BM, int BN, int FOLD>
 __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw, int lane, int m0, int n0, int kbase, int nkt, int step) {
     using C = MidCfg<BM, BN>;
-    // piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7)
-    const char* xp[C::XPW];
-    const char* wp[C::WPW];
+    // piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7).
+    // Addresses = a wave-uniform base (tile origin + K-tile, advanced by scalar adds) + per-lane 32-bit byte offsets that never change
+    // (rows past the edge are clamped to the last row: never stored)
+    int xo[C::XPW], wo[C::WPW];
 #pragma unroll
     for (int q = 0; q < C::XPW; ++q) {
         const int r = (lw * C::XPW + q) * 8 + (lane >> 3);
-        int grow = m0 + r;
-        grow = grow < a.M ? grow : a.M - 1;              // clamp: rows past the edge are never stored
-        xp[q] = reinterpret_cast<const char*>(a.X + (long)grow * a.ldx + kbase) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        const int rr = m0 + r < a.M ? r : a.M - 1 - m0;
+        xo[q] = rr * (int)a.ldx * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int q = 0; q < C::WPW; ++q) {
         const int r = (lw * C::WPW + q) * 8 + (lane >> 3);
-        int grow = n0 + r;
-        grow = grow < a.N ? grow : a.N - 1;
-        wp[q] = reinterpret_cast<const char*>(a.W + (long)grow * a.ldw + kbase) + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        const int rr = n0 + r < a.N ? r : a.N - 1 - n0;
+        wo[q] = rr * (int)a.ldw * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
-    auto issue = [&](int slot) {                         // the K-tile the pointers stand at -> stage `slot`; then advance one K-tile
+    const char* xbase = reinterpret_cast<const char*>(a.X + (long)m0 * a.ldx + kbase);
+    const char* wbase = reinterpret_cast<const char*>(a.W + (long)n0 * a.ldw + kbase);
+    auto issue = [&](int slot) {                         // the K-tile the bases stand at -> stage `slot`; then advance one K-tile
         char* st = smem + slot * C::STAGE;
 #pragma unroll
-        for (int q = 0; q < C::XPW; ++q) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xp[q],
+        for (int q = 0; q < C::XPW; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xbase + xo[q]),
                                              (__attribute__((address_space(3))) void*)(st + (lw * C::XPW + q) * 1024), 16, 0, 0);
-            xp[q] += MID_BK * 2;
-        }
 #pragma unroll
-        for (int q = 0; q < C::WPW; ++q) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wp[q],
+        for (int q = 0; q < C::WPW; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + wo[q]),
                                              (__attribute__((address_space(3))) void*)(st + C::XB + (lw * C::WPW + q) * 1024), 16, 0, 0);
-            wp[q] += MID_BK * 2;
-        }
+        xbase += MID_BK * 2; wbase += MID_BK * 2;
     };
     MID_STAMP_DECL();
     MID_STAMP(0);
     issue(0);
     if (nkt > 1) issue(1);
     MID_STAMP(1);
-    // K-tile 0 landed (K-tile 1 may still be in flight); the rest of the ring follows the barrier: the compute waves start earlier
+    // K-tile 0 landed (K-tile 1 may still be in flight); the rest of the ring follows the barrier: the compute waves start earlier.
+    // (Only K-tile 0 ahead of the barrier measured 1.5 % SLOWER per SDE step at the shipped 32-token config: tools/dbg/lib_ab.py.)
     if (nkt > 1) mid_wait_vmcnt<C::PPW>();
     else mid_wait_vmcnt<0>();
     MID_STAMP(2);
@@ -268,7 +268,8 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
         bias4[ni] = (a.bias && FOLD != MID_FOLD_CONSUMER) ? *reinterpret_cast<const f32x4*>(a.bias + nb + ni * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
         constexpr int RS = NT * 32 + 16;                 // staged row: NT*16 bf16 + 16 B pad
-        constexpr int CPR = NT * 2;                      // 16-B chunks per row (8 | 4)
+        constexpr int CHK = NT * 2;                      // 16-B chunks per row (8 | 6 | 4)
+        constexpr int CPR = NT == 2 ? 4 : 8;             // lanes per row (a power of two; NT = 3: lanes 6, 7 of each octet idle)
         constexpr int RPI = 64 / CPR;                    // rows per store instruction (8 | 16)
         f32x4 s4[NT];
         if constexpr (FOLD == MID_FOLD_CONSUMER) {       // this wave's columns of the S | C slices the loader waves left in the staging tails
@@ -307,8 +308,10 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
 #pragma unroll
             for (int it = 0; it < 16 / RPI; ++it) {
                 const int row = it * RPI + lane / CPR, ch = lane % CPR;
-                const bf16x8 d = *reinterpret_cast<const bf16x8*>(reg + row * RS + ch * 16);
-                if (m0 + mi * 16 + row < a.M) *reinterpret_cast<bf16x8*>(o + (long)row * a.ldo + ch * 8) = d;
+                if (CHK == CPR || ch < CHK) {
+                    const bf16x8 d = *reinterpret_cast<const bf16x8*>(reg + row * RS + ch * 16);
+                    if (m0 + mi * 16 + row < a.M) *reinterpret_cast<bf16x8*>(o + (long)row * a.ldo + ch * 8) = d;
+                }
             }
         }
     } else {
@@ -322,7 +325,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
         const bool shared_gate = has_gate && a.gate_sample_stride == 0;
         f32x4 g4 = {1.f, 1.f, 1.f, 1.f};
         if (shared_gate) g4 = *reinterpret_cast<const f32x4*>(gate + nb + ch * 4);
-        float* obase = reinterpret_cast<float*>(a.out) + ((EPI == EPI_F32 && a.splits > 1) ? (long)blockIdx.y * a.split_stride : 0L);
+        float* obase = reinterpret_cast<float*>(a.out);
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
         if constexpr (FOLD == MID_FOLD_PRODUCER) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(a.ln_scale + (long)step * a.ln_step_stride + nb + ch * 4);
@@ -406,10 +409,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int tile_m = a.col_major ? wgid % tiles_m : wgid / tiles_n, tile_n = a.col_major ? wgid / tiles_m : wgid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const bool split = (EPI == EPI_F32 && a.splits > 1);
-    const int ksplit = split ? a.K / a.splits : a.K;
-    const int kbase = split ? (int)blockIdx.y * ksplit : 0;
-    const int nkt = ksplit / MID_BK;
+    const int kbase = 0;
+    const int nkt = a.K / MID_BK;
     const int step = a.step_ptr ? *a.step_ptr : 0;       // device-side SDE step counter (scalar load, before any request of this kernel)
 
     if (wave >= 4) {                                     // loader waves: the operand stream, nothing else
@@ -445,12 +446,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             const char* wl = reinterpret_cast<const char*>(a.W + (long)(n0 + prow) * a.ldw + kbase);
             char* dst = smem_mid + C::RING + wave * 4096;
             int cnt = 0;
-            for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 8; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway; 8 x 256 B stay clear of the staging tails)
+            for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 6; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway; 6 x 256 B: the staging area's head)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wl + (long)j * (MID_BK * 2)),
                                                  (__attribute__((address_space(3))) void*)(dst + cnt * 256), 4, 0, 0);
         }
     }
 #endif
+    // (Also tried here: pulling the NEXT GEMM's weights towards the Infinity Cache, 1 / 256 of them per workgroup — 2.3 % SLOWER per SDE step
+    //  at the shipped 32-token config, 2.5 % at the ViPC share: the extra HBM requests compete with this kernel's own first K-tiles.)
     MID_BARRIER();                                       // prologue barrier: K-tile 0 has landed
     MID_STAMP(1);
     // BN = 128 residual epilogue: the wave's whole residual tile (BM rows x 32 columns fp32: 2 x 16 B per lane and 16-row pass) is requested
@@ -464,21 +467,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             for (int it = 0; it < 2; ++it) rpre[mi][it] = mid_resid_load<NT>(a, m0, n0 + wn * (BN / 4), lane, mi, it);
     }
 
-    if constexpr (BM == 128 && NT == 4) {
-        // K-tile = 4 blocks of 16 MFMAs: (half 0, rows 0-63), (half 0, rows 64-127), (half 1, rows 0-63), (half 1, rows 64-127);
+    if constexpr (BM == 128 && NT >= 3) {
+        // (NT = 4 | 3: BN = 256 | 192)  K-tile = 4 blocks of 4 NT MFMAs: (half 0, rows 0-63), (half 0, rows 64-127), (half 1, rows 0-63), (half 1, rows 64-127);
         // each block's fragments are read during the block before it
-        bf16x8 wa[4], wb[4], xa[4], xb[4];
-        auto ld_w = [&](bf16x8 (&w)[4], const char* st, int off) {
+        bf16x8 wa[NT], wb[NT], xa[4], xb[4];
+        auto ld_w = [&](bf16x8 (&w)[NT], const char* st, int off) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = *reinterpret_cast<const bf16x8*>(st + off + i * 2048);
+            for (int i = 0; i < NT; ++i) w[i] = *reinterpret_cast<const bf16x8*>(st + off + i * 2048);
         };
         auto ld_x = [&](bf16x8 (&x)[4], const char* st, int off, int part) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const bf16x8*>(st + off + (part * 4 + i) * 2048);
         };
-        auto mm = [&](const bf16x8 (&w)[4], const bf16x8 (&x)[4], int part) {
+        auto mm = [&](const bf16x8 (&w)[NT], const bf16x8 (&x)[4], int part) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][part * 4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], x[mi], acc[ni][part * 4 + mi], 0, 0, 0);
@@ -493,31 +496,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
         for (int kt = 0; kt + 1 < nkt; ++kt) {
             ld_x(xb, st, xb0, 1);
             mm(wa, xa, 0);
-            mid_interleave<4, 2>();
+            mid_interleave<4, 2, 4 * NT>();
             ld_w(wb, st, wb1); ld_x(xa, st, xb1, 0);
             mm(wa, xb, 1);
-            mid_interleave<8, 1>();
+            mid_interleave<NT + 4, 1, 4 * NT>();
             ld_x(xb, st, xb1, 1);                        // last read of this stage
             mm(wb, xa, 0);
-            mid_interleave<4, 2>();
+            mid_interleave<4, 2, 4 * NT>();
             MID_LGKM0();
             MID_BARRIER();                               // barrier kt: K-tile kt+1 landed; this stage may be refilled
             slot = slot + 1 == C::NS ? 0 : slot + 1;
             st = smem_mid + slot * C::STAGE;
             ld_w(wa, st, wb0); ld_x(xa, st, xb0, 0);
             mm(wb, xb, 1);
-            mid_interleave<8, 1>();
+            mid_interleave<NT + 4, 1, 4 * NT>();
             MID_LGKM0();                                 // (free behind the MFMAs; lets hipcc's wait insertion open the next trip with known counters)
         }
         ld_x(xb, st, xb0, 1);
         mm(wa, xa, 0);
-        mid_interleave<4, 2>();
+        mid_interleave<4, 2, 4 * NT>();
         ld_w(wb, st, wb1); ld_x(xa, st, xb1, 0);
         mm(wa, xb, 1);
-        mid_interleave<8, 1>();
+        mid_interleave<NT + 4, 1, 4 * NT>();
         ld_x(xb, st, xb1, 1);
         mm(wb, xa, 0);
-        mid_interleave<4, 2>();
+        mid_interleave<4, 2, 4 * NT>();
         mm(wb, xb, 1);
     } else if constexpr (BM == 64) {
         // 64 x 128 tile: a wave owns 64 rows x 32 columns (2 x 4 accumulator tiles), a K-tile is ONE block of 16 MFMAs; the whole next K-tile's
@@ -632,21 +635,21 @@ static int mid_env() {
 // Tile shape for (M, N): this path is bound by what a CU can take in through the L2 -> LDS DMA (~80 GB/s, profiles/r04_mid_stamps.txt), so
 // the cost of a shape is rounds x bytes per workgroup and K-tile ~ ceil(workgroups / 256) x (BM + BN).  -> (BM << 16) | BN, 0 = not taken.
 int ldt_gemm_mid_shape(int epi, const GemmArgs* a) {
-    const int mode = mid_env();                          // 0 off, 1 automatic; tools/dbg: 256 / 128 / 64 pin 128x256 / 128x128 / 64x128
+    const int mode = mid_env();                          // 0 off, 1 automatic; tools/dbg: 256 / 192 / 128 / 64 pin 128x256 / 128x192 / 128x128 / 64x128
     if (!mode) return 0;
     if (!(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32)) return 0;
     if (a->K % MID_BK != 0 || a->N % 128 != 0 || a->M < 64 || a->ldo % 8 != 0) return 0;
-    if (a->splits > 1 && (epi != EPI_F32 || a->K % (a->splits * MID_BK) != 0)) return 0;
     if (epi == EPI_RESID_F32 && (a->ldr % 4 != 0 || (a->gate && a->gate_sample_stride % 4 != 0))) return 0;
-    const long sp = a->splits > 1 ? a->splits : 1;
-    struct { int bm, bn; } cand[3] = {{128, 256}, {128, 128}, {64, 128}};
+    struct { int bm, bn; } cand[4] = {{128, 256}, {128, 192}, {128, 128}, {64, 128}};
+    const bool bf16_out = epi == EPI_BF16 || epi == EPI_GELU_BF16;
     if (mode == 256) return a->N % 256 == 0 ? (128 << 16) | 256 : 0;
     if (mode == 128) return (128 << 16) | 128;
     if (mode == 64) return (64 << 16) | 128;
     long best_cost = 0; int best = 0;
-    for (int i = 0; i < 3; ++i) {
-        if (a->N % cand[i].bn != 0) continue;
-        const long wgs = (long)((a->M + cand[i].bm - 1) / cand[i].bm) * (a->N / cand[i].bn) * sp;
+    if (mode == 192) return (a->N % 192 == 0 && bf16_out) ? (128 << 16) | 192 : 0;
+    for (int i = 0; i < 4; ++i) {
+        if (a->N % cand[i].bn != 0 || (cand[i].bn == 192 && !bf16_out)) continue;
+        const long wgs = (long)((a->M + cand[i].bm - 1) / cand[i].bm) * (a->N / cand[i].bn);
         if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) continue;
         const long cost = ((wgs + LDT_NUM_CUS - 1) / LDT_NUM_CUS) * (cand[i].bm + cand[i].bn);
         if (!best || cost < best_cost) { best = (cand[i].bm << 16) | cand[i].bn; best_cost = cost; }
@@ -662,13 +665,13 @@ static int mid_launch_t(const GemmArgs* a_in, hipStream_t stream) {
     static const int map_env = getenv("LDT_GEMM_MID_MAP") ? atoi(getenv("LDT_GEMM_MID_MAP")) : -1;   // tools/dbg: 0 row-major, 1 column-major
     a.col_major = map_env >= 0 ? map_env : 1;
     LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI, BM, BN>), C::LDS, "gemm_mid");
-    const unsigned sp = (EPI == EPI_F32 && a.splits > 1) ? (unsigned)a.splits : 1u;
-    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI, BM, BN>), dim3((unsigned)(tm * tn), sp), dim3(512), C::LDS, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI, BM, BN>), dim3((unsigned)(tm * tn)), dim3(512), C::LDS, stream, a);
     return ldt_check_launch("gemm_bf16_nt_mid");
 }
 
 int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream) {
     const int bm = shape >> 16, bn = shape & 0xffff;
+    if (bn == 192) return epi == EPI_BF16 ? mid_launch_t<EPI_BF16, 128, 192>(a, stream) : mid_launch_t<EPI_GELU_BF16, 128, 192>(a, stream);
 #define MID_CASE(E)                                                                                            \
     case E: return bm == 64 ? mid_launch_t<E, 64, 128>(a, stream) : bn == 256 ? mid_launch_t<E, 128, 256>(a, stream) \
                                                                                : mid_launch_t<E, 128, 128>(a, stream)
@@ -710,9 +713,12 @@ bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a_in, hipStream_t stream, 
     // consumer: the loader waves' statistics pass assumes the whole ring is in flight and <= 32 partials per row
     if (bm != 128 || a.stats_parts > 32 || a.stats_parts * 32 != a.K || a.K / MID_BK < MidCfg<128, 256>::NS + 2) return false;
     if (epi == EPI_BF16)
-        *status = bn == 256 ? mid_fold_launch_t<EPI_BF16, 128, 256, MID_FOLD_CONSUMER>(a, stream) : mid_fold_launch_t<EPI_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
+        *status = bn == 256 ? mid_fold_launch_t<EPI_BF16, 128, 256, MID_FOLD_CONSUMER>(a, stream)
+                : bn == 192 ? mid_fold_launch_t<EPI_BF16, 128, 192, MID_FOLD_CONSUMER>(a, stream)
+                            : mid_fold_launch_t<EPI_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
     else if (epi == EPI_GELU_BF16)
         *status = bn == 256 ? mid_fold_launch_t<EPI_GELU_BF16, 128, 256, MID_FOLD_CONSUMER>(a, stream)
+                : bn == 192 ? mid_fold_launch_t<EPI_GELU_BF16, 128, 192, MID_FOLD_CONSUMER>(a, stream)
                             : mid_fold_launch_t<EPI_GELU_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
     else return false;
     return true;

@@ -29,8 +29,6 @@ struct GemmArgs {
     int group_m;                        // 256-tile kernel: row panels per group of the tile order (set by the launcher)
     int dbg;                            // tools/dbg only (LDT_DBG_EPI bits: 1 no residual read, 2 no fp32 store, 4 no xs store, 8 no statistics)
     int max_wgs;                        // 256-tile kernel: cap on the persistent grid (0 = one workgroup per CU); sub-batch streams use 128
-    // ---- split-K (v1 kernel, EPI_F32 only): blockIdx.y = split s computes k in [s K/splits, (s+1) K/splits) into out + s * split_stride
-    int splits; long split_stride;
     int col_major;                      // v1 kernel: tile order (set by the launcher; see gemm_bf16_nt_kernel)
 };
 
@@ -42,9 +40,6 @@ struct LnArgs {
     long mod_sample_stride; int rows_per_sample;
     const int* step_ptr; long mod_step_stride;
     long M; int C;
-    // ---- residual + split-K reduction folded into the LayerNorm (small-M regime): first x <- x + gate * (sum_s part[s] + pbias), stored
-    // back in place, then the LayerNorm of the new row.  gate uses the same (step, sample) addressing as shift / scale.
-    const float* part; int nparts; long part_stride; const float* pbias; const float* gate; float* x_out;
 };
 
 struct AttnArgs {

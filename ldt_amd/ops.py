@@ -131,30 +131,6 @@ def layernorm_modulate(x, w=None, b=None, shift=None, scale=None, mod_sample_str
     return out
 
 
-def gemm_bf16_splitk(x, w, splits):
-    """fp32 [splits, M, N]: raw partial products of x[M,K] @ w[N,K]^T over `splits` equal K ranges (small-batch residual GEMMs)."""
-    _need(x, torch.bfloat16, "x"); _need(w, torch.bfloat16, "w"); _rowmajor(x, "x"); _rowmajor(w, "w")
-    M, K = x.shape
-    N = w.shape[0]
-    parts = torch.empty((splits, M, N), dtype=torch.float32, device=x.device)
-    check(lib().ldt_gemm_bf16_splitk(_p(x), x.stride(0), _p(w), w.stride(0), _p(parts), int(splits), M, N, K, stream_ptr()), "ldt_gemm_bf16_splitk")
-    return parts
-
-
-def layernorm_modulate_resid_(x, parts, bias=None, gate=None, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=0, step_ptr=None,
-                              mod_step_stride=0):
-    """In place x += gate * (parts.sum(0) + bias) (fp32 [M,C]), then -> bf16 LN(x)(1 + scale) + shift (returned)."""
-    _need(x, torch.float32, "x"); _need(parts, torch.float32, "parts")
-    M, Cc = x.shape
-    if not x.is_contiguous() or not parts.is_contiguous() or tuple(parts.shape[1:]) != (M, Cc):
-        raise ValueError("layernorm_modulate_resid_: x [M,C] and parts [S,M,C] must be contiguous")
-    out = torch.empty((M, Cc), dtype=torch.bfloat16, device=x.device)
-    check(lib().ldt_layernorm_modulate_resid(_p(x), _p(out), out.stride(0), _p(parts), parts.shape[0], _p(bias), _p(gate), _p(shift), _p(scale),
-                                             mod_sample_stride, rows_per_sample or M, _p(step_ptr), mod_step_stride, M, Cc, stream_ptr()),
-          "ldt_layernorm_modulate_resid")
-    return out
-
-
 def attention_fwd(q, k, v, B, H, Nq, Nk, head_dim, out=None):
     """q [B*Nq, >=H*Dh] , k/v [B*Nk, ...] bf16 row views (heads at column h*Dh) -> O [B,H,Nq,Dh] bf16."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):

@@ -186,8 +186,6 @@ class Score(nn.Module):
             self._cond_cache = {key: (kv, S, pts_cond)}
         return self._cond_cache[key][:2]
 
-    SPLITK_MAX_ROWS, SPLITK_PARTS = 4096, 8      # ldt_score_plan.splitk_ws: offered to the C++ forward for batches of <= 4096 token rows
-
     def _workspace(self, B, T, slot=0):
         """Activation buffers of a (B, T) batch; `slot` separates the sub-batches that run concurrently on their own streams."""
         k = (B, T, self._device(), slot)
@@ -202,8 +200,6 @@ class Score(nn.Module):
                 "Ob": torch.empty((M, D), **bf), "U": torch.empty((M, self.Transformer[0].mlp.out.in_channels), **bf),
                 "stats": torch.empty((max(D // 32, 1), M, 2), dtype=torch.float32, device=dev),   # [D/256] (256-tile kernels) or [D/32] (small-batch kernels) partials per row
             }
-            if M <= self.SPLITK_MAX_ROWS and D % 256 == 0 and D <= 1024:          # small batch: split-K partials of the residual GEMMs
-                self._ws[k]["P"] = torch.empty((self.SPLITK_PARTS, M, D), dtype=torch.float32, device=dev)
         return self._ws[k]
 
     def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0, monitor=None):
@@ -225,8 +221,6 @@ class Score(nn.Module):
         p.mod, p.mod_step_stride, p.mod_sample_stride = mod.data_ptr(), mod_step_stride, mod_sample_stride
         for nm in ("xin", "X", "Hb", "QKV", "Ob", "U"):
             setattr(p, nm, W[nm].data_ptr())
-        if "P" in W:
-            p.splitk_ws, p.splitk_parts = W["P"].data_ptr(), W["P"].shape[0]
         if kv_cond:
             p.cond_tokens = cond_tokens
             for l, kv in kv_cond.items():
@@ -288,9 +282,12 @@ class Score(nn.Module):
         t256 = lambda n: -(-M // 256) * -(-n // 256)
         small = M % 128 == 0 and not int(os.environ.get("LDT_GEMM_FORCE", "0")) and all(t256(n) * 8 < lim * 5 for n in (D, 3 * D, F))
         if small:
-            # measured neutral at the shipped 32-token config (B = 64: 3.04 vs 3.05 ms per SDE step; producers +2 us, consumers +2-5 us
-            # against two 5.5-us LayerNorm launches, tools/dbg/fold_small_ab.py): opt-in
-            return mode == 2 or bool(int(os.environ.get("LDT_LN_FOLD_SMALL", "0")))
+            # On the mid-size tile kernels (csrc/gemm_mid.hip, default for these batches) the folded forms pay: the loader waves form the row
+            # statistics while the ring fills, so a consumer costs +1 us and a producer +2 us against two 5.8-us LayerNorm launches
+            # (shipped 32-token config, B = 64: 98.5 -> 92.5 us per block, profiles/r04_t32_kernel_sequence.txt).  On the round-3 small-tile
+            # kernels (LDT_GEMM_MID=0) it measured neutral (3.04 vs 3.05 ms per SDE step) and stays opt-in there.
+            dflt = "1" if int(os.environ.get("LDT_GEMM_MID", "1")) else "0"
+            return mode == 2 or bool(int(os.environ.get("LDT_LN_FOLD_SMALL", dflt)))
         if M % 256:
             return False
         return mode == 2 or (M // 256) * (D // 256) * 8 >= lim * 5

@@ -36,8 +36,8 @@ def test_binding_covers_header(built):
 
 
 def test_plan_struct_layout_matches_header(built):
-    # 8 int32 + (2 + 8*64 + 2) pointers + 3*64 pointers + 2 int32 + ptr + 2 int64 + 6 pointers + (fold ptr, int64, stats ptr) + 2 int32 + fold_monitor ptr + (splitk ptr, 2 int32)
-    assert ctypes.sizeof(built.ScorePlan) == 8 * 4 + (2 + 8 * built.MAX_BLOCKS + 2 + 3 * built.MAX_BLOCKS + 1 + 1 + 2 + 6 + 3 + 1 + 1 + 2) * 8
+    # 8 int32 + (2 + 8*64 + 2) pointers + 3*64 pointers + 2 int32 + ptr + 2 int64 + 6 pointers + (fold ptr, int64, stats ptr) + 2 int32 + fold_monitor ptr
+    assert ctypes.sizeof(built.ScorePlan) == 8 * 4 + (2 + 8 * built.MAX_BLOCKS + 2 + 3 * built.MAX_BLOCKS + 1 + 1 + 2 + 6 + 3 + 1 + 1) * 8
 
 
 def test_argument_errors_are_reported_not_crashed(built):

@@ -62,22 +62,22 @@ def test_fullsize_teacher_forced_b64(full):
 
 
 def test_fullsize_shipped_32_tokens_b64(full, monkeypatch):
-    """The shipped YAML's regime at production width: B = 64 shapes x 32 latent tokens = 2048 token rows — every GEMM on the small-tile
-    kernels (column-major tile order for the wide outputs), resident attention — teacher-forced against the oracle; and the same
-    forward with the LayerNorms folded into those kernels' epilogues (row statistics per 32 columns; opt-in, forced here)."""
+    """The shipped YAML's regime at production width: B = 64 shapes x 32 latent tokens = 2048 token rows — every GEMM on the mid-size tile
+    kernels (csrc/gemm_mid.hip: 128 x 192 / 128 x 256 / 64 x 128 tiles), resident attention — teacher-forced against the oracle, with the
+    LayerNorm kernels (LDT_LN_FOLD_SMALL=0) and with the LayerNorms folded into the GEMM epilogues (row statistics per 32 columns: the
+    production decision for this batch since round 4)."""
     O, cfg, score = full["O"], full["cfg"], full["score"]
     B, T, z = 64, 32, cfg.score.z_dim
     g = torch.Generator().manual_seed(33)
     x = torch.randn(B, T, z, generator=g)
     t = 0.61
     monkeypatch.delenv("LDT_LN_FOLD", raising=False)
-    monkeypatch.delenv("LDT_LN_FOLD_SMALL", raising=False)
-    assert not score.can_fold(B, T)                               # the production decision for this batch: LayerNorm kernels
+    monkeypatch.setenv("LDT_LN_FOLD_SMALL", "0")
+    assert not score.can_fold(B, T)
     plain = score.forward_shared_t(x.cuda(), t)
-    monkeypatch.setenv("LDT_LN_FOLD", "2")
-    assert score.can_fold(B, T)
+    monkeypatch.delenv("LDT_LN_FOLD_SMALL")
+    assert score.can_fold(B, T)                                   # the production decision for this batch: folded
     folded = score.forward_shared_t(x.cuda(), t)
-    monkeypatch.delenv("LDT_LN_FOLD")
     with torch.no_grad():
         ref = O.score_forward(full["sd_s"], cfg.score, x, torch.full((B,), t))
     e_p, e_f = rel_mse(plain.cpu(), ref), rel_mse(folded.cpu(), ref)

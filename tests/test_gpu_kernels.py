@@ -73,11 +73,13 @@ def test_gemm_all_epilogues(M, N, K):
                                    (2048, 4096, 64), (2048, 4096, 128), (2048, 4096, 192), (1152, 1536, 64), (1152, 1536, 192),
                                    (1000, 2304, 320), (1960, 4096, 320), (4096, 1024, 1024),
                                    # 64 x 128 tiles (4-stage ring, K-tile-deep register double buffering): 1..5 K-tiles, ragged rows
-                                   (2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (2048, 1024, 320), (1000, 1024, 448)])
+                                   (2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (2048, 1024, 320), (1000, 1024, 448),
+                                   # 128 x 192 tiles (bf16-output epilogues; the fp32 ones of these shapes take another form)
+                                   (2048, 3072, 64), (2048, 3072, 192), (1990, 3072, 320)])
 def test_gemm_mid_kernel(M, N, K):
     """The mid-size tile kernel (csrc/gemm_mid.hip: 128 x 256 / 128 x 128 / 64 x 128 tiles, loader waves, 3- / 4-stage ring) on the shapes the launcher hands
     it — incl. 1 / 2 / 3 / 5 K-tiles (prologue and drain paths of the ring), a ragged last row tile, a step-indexed shared gate, a per-sample
-    gate and split-K partials — vs fp64 on the same bf16 operands."""
+    gate — vs fp64 on the same bf16 operands."""
     from ldt_amd._lib import EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_RESID_F32
     g = torch.Generator().manual_seed(M * 3 + N + K)
     x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
@@ -103,13 +105,6 @@ def test_gemm_mid_kernel(M, N, K):
         rd = dev(resid.clone())
         ops.gemm_bf16(xd, wd, bd, EPI_RESID_F32, out=rd, resid=rd, gate=dev(gate)[:, N:2 * N], gate_sample_stride=3 * N, rows_per_sample=8)
         assert rel_mse(rd.cpu(), resid.double() + gate[:, N:2 * N].double().repeat_interleave(8, 0) * ref) < 1e-9
-    for splits in (2, 4):
-        if K % (splits * 64) == 0:
-            parts = ops.gemm_bf16_splitk(xd, wd, splits)
-            assert parts.shape == (splits, M, N)
-            assert rel_mse(parts.sum(0).cpu(), x.double() @ w.double().T) < 1e-9
-            ks = K // splits
-            assert rel_mse(parts[1].cpu(), x[:, ks:2 * ks].double() @ w[:, ks:2 * ks].double().T) < 1e-9
 
 
 @pytest.mark.parametrize("M,D,N2,gelu,granule", [(512, 1024, 768, False, 256), (256, 512, 2048, True, 256), (768, 256, 256, False, 256),
@@ -600,68 +595,3 @@ torch.save(outs, sys.argv[1])
         for k in base:
             assert torch.equal(cur[k], base[k]), "LDT_GEMM_FL=%s LDT_RESID_RING=%s differs from the v2 register-epilogue path in %s" % (key + (k,))
     assert bool(torch.isfinite(base["x1"]).all()) and float(base["x1"].abs().mean()) > 0.1 and float(base["u"].float().abs().mean()) > 0.01
-
-
-@pytest.mark.parametrize("M,N,K,splits", [(2048, 1024, 4096, 4), (1024, 1024, 1024, 4), (2048, 1024, 1024, 2), (384, 256, 512, 8)])
-def test_splitk_gemm_and_residual_layernorm(M, N, K, splits):
-    """Small-batch regime (T = 32 latents): the residual GEMMs run split over K into fp32 partials and the LayerNorm that follows does
-    x += gate * (sum of partials + bias) before normalising (include/ldt_hip.h) — vs the unsplit RESID_F32 GEMM + LayerNorm kernels
-    and vs fp64."""
-    from ldt_amd._lib import EPI_RESID_F32
-    g = torch.Generator().manual_seed(M + N + K + splits)
-    a = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5); b = torch.randn(N, generator=g)
-    x0 = torch.randn(M, N, generator=g)
-    rps = 128
-    gate = torch.randn(M // rps, N, generator=g); sh = 0.3 * torch.randn(M // rps, N, generator=g); sc = 0.3 * torch.randn(M // rps, N, generator=g)
-    parts = ops.gemm_bf16_splitk(dev(a, torch.bfloat16), dev(w, torch.bfloat16), splits)
-    ks = K // splits
-    for s_ in range(splits):
-        ref = a[:, s_ * ks:(s_ + 1) * ks].double() @ w[:, s_ * ks:(s_ + 1) * ks].double().T
-        assert rel_mse(parts[s_].cpu(), ref) < 1e-9
-    xd = dev(x0.clone())
-    h = ops.layernorm_modulate_resid_(xd, parts, bias=dev(b), gate=dev(gate), shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
-    xref = x0.double() + gate.double().repeat_interleave(rps, 0) * (a.double() @ w.double().T + b.double())
-    assert rel_mse(xd.cpu(), xref) < 1e-10
-    ln = (xref - xref.mean(1, keepdim=True)) / torch.sqrt(xref.var(1, unbiased=False, keepdim=True) + 1e-6)
-    href = ln * (1 + sc.double().repeat_interleave(rps, 0)) + sh.double().repeat_interleave(rps, 0)
-    assert rel_mse(h.float().cpu(), href) < 1e-5
-    # the unsplit kernels on the same inputs: same bf16 output up to fp32 summation order
-    x1 = dev(x0.clone())
-    ops.gemm_bf16(dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(b), EPI_RESID_F32, out=x1, resid=x1, gate=dev(gate), gate_sample_stride=N, rows_per_sample=rps)
-    h1 = ops.layernorm_modulate(x1, shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
-    assert rel_mse(xd.cpu(), x1.cpu()) < 1e-12 and rel_mse(h.float().cpu(), h1.float().cpu()) < 1e-6
-    again = ops.layernorm_modulate_resid_(dev(x0.clone()), parts, bias=dev(b), gate=dev(gate), shift=dev(sh), scale=dev(sc), mod_sample_stride=N, rows_per_sample=rps)
-    assert torch.equal(again, h)                                      # fixed summation order
-
-
-def test_score_forward_with_splitk_path_matches_default(tmp_path):
-    """The opt-in split-K orchestration of the Score forward (LDT_SPLITK, csrc/api.hip: fc_o / mlp.out as fp32 partials, the residual
-    add + reduction inside the following LayerNorm, incl. the FinalLayer's) equals the default path up to fp32 summation order, for the
-    batch-shared (fused-loop) and the per-sample AdaLN addressing.  Hidden 1024, 3 blocks, M = 1024 rows; child processes (the
-    switch is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    child = r'''
-import sys, torch
-sys.path.insert(0, %r)
-import ldt_amd
-cfg = ldt_amd.airplane_config(latent_tokens=32, sample_N=10, **{"score.num_blocks": 3})
-torch.manual_seed(3)
-score = ldt_amd.Score(cfg.score).cuda()
-g = torch.Generator().manual_seed(1)
-x = torch.randn(32, 32, cfg.score.z_dim, generator=g).cuda()
-t = (torch.rand(32, generator=g) * 0.9 + 0.05).cuda()
-torch.save(dict(shared=score.forward_shared_t(x, 0.4).cpu(), per_sample=score(x, t).cpu()), sys.argv[1])
-''' % ROOT
-    res = {}
-    for sk in ("0", "1", "4"):
-        out = tmp_path / ("sk%s.pt" % sk)
-        r = subprocess.run([sys.executable, "-c", child, str(out)], env=dict(os.environ, LDT_SPLITK=sk), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[sk] = torch.load(out)
-    for sk in ("1", "4"):
-        for k in ("shared", "per_sample"):
-            e = rel_mse(res[sk][k], res["0"][k])
-            assert 0 < e < 1e-6, (sk, k, e)       # taken (not bit-identical); fp32 summation order flips a few bf16 roundings downstream (1e-8)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole-loop A/B of two builds of libldt_hip.so on one box: runs `sample()` (N SDE steps, B=64, T=256) in a child
-process per library, alternating, and prints ms per step.   usage: lib_ab.py N libA.so libB.so [rounds]"""
+process per library, alternating, and prints ms per step (AB_TOKENS / AB_BATCH in the environment pick another workload).   usage: lib_ab.py N libA.so libB.so [rounds]"""
 import os, subprocess, sys
 N, libs = sys.argv[1], sys.argv[2:4]
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 2
@@ -9,13 +9,14 @@ import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import ldt_amd
 N = int(sys.argv[1])
-cfg = ldt_amd.airplane_config(latent_tokens=256, sample_N=N)
+T = int(os.environ.get("AB_TOKENS", "256")); B = int(os.environ.get("AB_BATCH", "64"))
+cfg = ldt_amd.airplane_config(latent_tokens=T, sample_N=N)
 torch.manual_seed(0)
 score = ldt_amd.Score(cfg.score); comp = ldt_amd.Compressor(cfg.compressor); comp.init()
 tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
 best = 1e9
 for r in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); tr.sample(64); torch.cuda.synchronize()
+    torch.cuda.synchronize(); t0 = time.perf_counter(); tr.sample(B); torch.cuda.synchronize()
     if r: best = min(best, time.perf_counter() - t0)
 print("%.4f" % (1e3 * best / N))
 '''

@@ -1,5 +1,5 @@
 """tools/dbg: the four GEMMs of a Score block at M = 2048 / 1024 / 4096 — mid-size tile kernel (csrc/gemm_mid.hip) against the 2-phase v1
-kernels (LDT_GEMM_MID=0), alternating child processes, plus split-K forms of the residual GEMMs.  `python tools/dbg/mid_bench.py`"""
+kernels (LDT_GEMM_MID=0), alternating child processes.  `python tools/dbg/mid_bench.py`"""
 import os, sys, subprocess
 sys.path.insert(0, '.')
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -40,10 +40,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             us = timeit(lambda: ops.gemm_bf16(x, w, b, epi, **kw))
             usc = timeit(lambda: ops.gemm_bf16(x, w, b, epi, **kw), flush=True)
             line += "  %s %.1f us (%.0f TF; cold %.1f)" % (name, us, 2.0 * M * N * K / us / 1e6, usc)
-            if f32:
-                for sp in (2, 4):
-                    us = timeit(lambda: ops.gemm_bf16_splitk(x, w, sp))
-                    line += " [splitK%d %.1f]" % (sp, us)
         print(line, flush=True)
 else:
     for rep in range(2):
