@@ -298,10 +298,17 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         if (fold && l > 0) {                                    // Hb = x (1 + scale_msa) and the row statistics came from block l-1's mlp.out
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, nullptr, p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, step_ptr, 0, M, 3 * D, D,
                         nullptr, 0, nullptr, 0, nullptr, p->stats, sparts, fl, fl + 3L * D, fstep};
-            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs;
+            // 32-token samples: projection + attention in one launch (gemm_mid.hip, mid_epilogue_attn): q | k | v never reach HBM
+            gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
+            int fst = LDT_OK;
+            if (fold_v1 && ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, true, s, &fst)) { TRY(fst); }
+            else {
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+            }
         } else {
         LnArgs n1{p->X, D, BFM(p->Hb), D, nullptr, nullptr, m, m + D, sstr, T, step_ptr, tstr, M, D};
         LAUNCH(LDT_PROF_LN, ldt_ln_launch(&n1, s));
@@ -314,10 +321,16 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
         } else {                                                // self-attention: fused q|k|v projection of the modulated x
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
-            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs;
+            gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
+            int fst = LDT_OK;
+            if (ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, false, s, &fst)) { TRY(fst); }   // 32-token samples: projection + attention in one launch
+            else {
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+            }
         }
         }
         if (fold) {

@@ -109,7 +109,10 @@ extern "C" int ldt_dbg_mid_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 #endif
 
 // ---------------------------------------------------------------------------------------------- loader waves
-template <int BM, int BN, int FOLD>
+// ATTN (fused QKV + attention, BN = 192): tile column c of head h = tile_n is output column / W row (c / 64) * hidden + h * 64 + c % 64
+__device__ __forceinline__ int mid_attn_col(int c, int h, int hidden) { return (c >> 6) * hidden + h * 64 + (c & 63); }
+
+template <int BM, int BN, int FOLD, bool ATTN>
 __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw, int lane, int m0, int n0, int kbase, int nkt, int step) {
     using C = MidCfg<BM, BN>;
     // piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7).
@@ -125,11 +128,11 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
 #pragma unroll
     for (int q = 0; q < C::WPW; ++q) {
         const int r = (lw * C::WPW + q) * 8 + (lane >> 3);
-        const int rr = n0 + r < a.N ? r : a.N - 1 - n0;
+        const int rr = ATTN ? mid_attn_col(r, n0 / BN, a.N / 3) : (n0 + r < a.N ? r : a.N - 1 - n0);
         wo[q] = rr * (int)a.ldw * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     const char* xbase = reinterpret_cast<const char*>(a.X + (long)m0 * a.ldx + kbase);
-    const char* wbase = reinterpret_cast<const char*>(a.W + (long)n0 * a.ldw + kbase);
+    const char* wbase = reinterpret_cast<const char*>(a.W + (ATTN ? 0L : (long)n0 * a.ldw) + kbase);
     auto issue = [&](int slot) {                         // the K-tile the bases stand at -> stage `slot`; then advance one K-tile
         char* st = smem + slot * C::STAGE;
 #pragma unroll
@@ -182,7 +185,8 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
         {
             constexpr int Q = 2 * BN;                    // bytes of [S | C] per loader wave: waves 0, 1 -> S, waves 2, 3 -> C
             const long fst = (long)step * a.fold_step_stride;
-            const float* src = (lw < 2 ? a.fold_S : a.fold_C) + fst + n0 + (lw & 1) * (Q / 4) + lane * 4;
+            const int c0 = (lw & 1) * (Q / 4) + lane * 4;    // tile column of this lane's 16 B
+            const float* src = (lw < 2 ? a.fold_S : a.fold_C) + fst + (ATTN ? mid_attn_col(c0 < BN ? c0 : 0, n0 / BN, a.N / 3) : n0 + c0);
             char* dst = smem + C::RING + (lw < 2 ? MID_S_OFF : MID_C_OFF) + (lw & 1) * Q;
             if (lane * 16 < Q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -392,9 +396,112 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused self-attention epilogue
+// QKV projection + attention in one launch for the shipped 32-token regime (model/layers.py:183-200 with N = M = 32, head dim 64).  The 128 x 192
+// tile is [q | k | v] of ONE head for FOUR whole samples: the finished projections (bias or LN-folded form applied) go to LDS as bf16 rows — the
+// operand ring is idle by then — and compute wave s runs sample s: S^T = K Q^T (8 MFMAs), the softmax over the 32 keys of a query (8 values
+// in the lane + two cross-lane steps), O^T = V^T P^T (8 MFMAs; the key order inside the 32-deep contraction is the accumulator layout's, applied
+// to both operands, so P never leaves its registers), O / l -> attn_o[B][H][32][64].  The q | k | v rows are never written to HBM and the
+// attention launch of the block is gone (6.5 us + a 12.6 MB round trip per block at B = 64).
+#define MID_T_STRIDE 400             /* bytes per staged row (192 bf16 + pad): conflict-free 16-B fragment reads */
+template <int FOLD>
+__device__ __forceinline__ void mid_epilogue_attn(const GemmArgs& a, f32x4 (&acc)[3][8], int m0, int head, int wn, int lane, char* tq,
+                                                  const char* stage_base) {
+    const int lrow = lane & 15, lchk = lane >> 4;
+    const int hidden = a.N / 3;
+    // ---- 1. finish the projection, bf16 rows into tq[128][192]
+    f32x4 add4[3], s4[3];
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni) {
+        const int c = wn * 48 + ni * 16 + lchk * 4;
+        if constexpr (FOLD == MID_FOLD_CONSUMER) {
+            s4[ni] = *reinterpret_cast<const f32x4*>(stage_base + MID_S_OFF + c * 4);
+            add4[ni] = *reinterpret_cast<const f32x4*>(stage_base + MID_C_OFF + c * 4);
+        } else {
+            s4[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            add4[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + mid_attn_col(c, head, hidden)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        f32x2 rn = {1.f, 0.f};
+        if constexpr (FOLD == MID_FOLD_CONSUMER) rn = *reinterpret_cast<const f32x2*>(stage_base + MID_RS_OFF + (mi * 16 + lrow) * 8);
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            f32x4 v = acc[ni][mi];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rn[0] * v[r] + (rn[1] * s4[ni][r] + add4[ni][r]);
+            const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(tq + (mi * 16 + lrow) * MID_T_STRIDE + (wn * 48 + ni * 16 + lchk * 4) * 2) = pk;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MID_BARRIER();                                       // the four compute waves (the loader waves have ended): the tile is complete
+    // ---- 2. wave wn = sample wn: rows [32 wn, +32)
+    const char* ts = tq + wn * 32 * MID_T_STRIDE;
+    f32x4 st[2][2];                                      // [key tile][query tile]: lane holds S[key = kt*16 + lchk*4 + r][query = qt*16 + lrow]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) st[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 kf[2], qf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kf[t] = *reinterpret_cast<const bf16x8*>(ts + (t * 16 + lrow) * MID_T_STRIDE + (64 + ks * 32 + lchk * 8) * 2);
+            qf[t] = *reinterpret_cast<const bf16x8*>(ts + (t * 16 + lrow) * MID_T_STRIDE + (ks * 32 + lchk * 8) * 2);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], st[kt][qt], 0, 0, 0);
+    }
+    // softmax over the 32 keys of each query (qt, lrow): 8 values in this lane, the rest in lanes lrow + 16 j
+    const float cs = a.attn_scale_log2e;
+    float linv[2];
+    bf16x8 pf[2];                                        // P^T operand: k-slot j of lane group lchk = key (j < 4 ? lchk*4 + j : 16 + lchk*4 + j - 4)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = fmaxf(fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3])),
+                         fmaxf(fmaxf(st[1][qt][0], st[1][qt][1]), fmaxf(st[1][qt][2], st[1][qt][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * cs;
+        float p[8], l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[kt * 4 + r] = __builtin_amdgcn_exp2f(st[kt][qt][r] * cs - mc); l += p[kt * 4 + r]; }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        linv[qt] = 1.0f / l;
+        pf[qt] = (bf16x8){(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3], (bf16_t)p[4], (bf16_t)p[5], (bf16_t)p[6], (bf16_t)p[7]};
+    }
+    // O^T[d][query] = sum_key V[key][d] P[query][key]: A operand = V^T rows d = dt*16 + lrow with the same key order in its k-slots
+    bf16_t* ob = a.attn_o + (((long)(m0 / 32 + wn) * (hidden / 64) + head) * 32) * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bf16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = (j < 4) ? lchk * 4 + j : 16 + lchk * 4 + (j - 4);
+            vf[j] = *reinterpret_cast<const bf16_t*>(ts + key * MID_T_STRIDE + (128 + dt * 16 + lrow) * 2);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // lane holds O[query = qt*16 + lrow][d = dt*16 + lchk*4 + r]
+            const bf16x4 pk = {(bf16_t)(o[0] * linv[qt]), (bf16_t)(o[1] * linv[qt]), (bf16_t)(o[2] * linv[qt]), (bf16_t)(o[3] * linv[qt])};
+            *reinterpret_cast<bf16x4*>(ob + (qt * 16 + lrow) * 64 + dt * 16 + lchk * 4) = pk;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
-template <int EPI, int BM, int BN, int FOLD = MID_FOLD_NONE>
+template <int EPI, int BM, int BN, int FOLD = MID_FOLD_NONE, bool ATTN = false>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a) {
+    static_assert(!ATTN || (EPI == EPI_BF16 && BM == 128 && BN == 192 && FOLD != MID_FOLD_PRODUCER), "fused attention: the 128 x 192 bf16 form");
     using C = MidCfg<BM, BN>;
     constexpr int NT = C::NT, MT = C::MT;
     extern __shared__ __attribute__((aligned(16))) char smem_mid[];
@@ -414,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     const int step = a.step_ptr ? *a.step_ptr : 0;       // device-side SDE step counter (scalar load, before any request of this kernel)
 
     if (wave >= 4) {                                     // loader waves: the operand stream, nothing else
-        mid_loader<BM, BN, FOLD>(a, smem_mid, wave - 4, lane, m0, n0, kbase, nkt, step);
+        mid_loader<BM, BN, FOLD, ATTN>(a, smem_mid, wave - 4, lane, m0, n0, kbase, nkt, step);
         return;
     }
 
@@ -443,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     {
         const int prow = wn * 64 + lane;                 // row of the panel this lane touches (BN = 128: waves 0, 1 cover it)
         if (prow < BN) {
-            const char* wl = reinterpret_cast<const char*>(a.W + (long)(n0 + prow) * a.ldw + kbase);
+            const char* wl = reinterpret_cast<const char*>(a.W + (long)(ATTN ? mid_attn_col(prow, tile_n, a.N / 3) : n0 + prow) * a.ldw + kbase);
             char* dst = smem_mid + C::RING + wave * 4096;
             int cnt = 0;
             for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 6; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway; 6 x 256 B: the staging area's head)
@@ -615,7 +722,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    mid_epilogue<EPI, BM, BN, FOLD>(a, acc, m0, n0 + wn * (BN / 4), wn, lane, smem_mid + C::RING + wave * 4096, smem_mid + C::RING, rpre, step);
+    if constexpr (ATTN) {
+        // every compute wave is past its last ring read before the ring becomes the q | k | v tile
+        MID_BARRIER();
+        mid_epilogue_attn<FOLD>(a, acc, m0, tile_n, wn, lane, smem_mid, smem_mid + C::RING);
+    } else
+        mid_epilogue<EPI, BM, BN, FOLD>(a, acc, m0, n0 + wn * (BN / 4), wn, lane, smem_mid + C::RING + wave * 4096, smem_mid + C::RING, rpre, step);
 #ifdef MID_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MID_STAMP(3);
@@ -721,5 +833,28 @@ bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a_in, hipStream_t stream, 
                 : bn == 192 ? mid_fold_launch_t<EPI_GELU_BF16, 128, 192, MID_FOLD_CONSUMER>(a, stream)
                             : mid_fold_launch_t<EPI_GELU_BF16, 128, 128, MID_FOLD_CONSUMER>(a, stream);
     else return false;
+    return true;
+}
+
+// QKV projection + self-attention in one launch (mid_epilogue_attn): 32-token samples, head dim 64, N = 3 * hidden with hidden % 64 == 0,
+// whole 128-row tiles (four samples each).  `folded`: a = the LN-folded consumer's arguments (stats per 32 columns).  LDT_QKV_ATTN=0: off (A/B).
+template <int FOLD>
+static int mid_qkv_attn_launch(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = MidCfg<128, 192>::LDS;
+    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, true>), lds, "gemm_mid(qkv+attention)");
+    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, true>), dim3((unsigned)((a.M / 128) * (a.N / 192))), dim3(512), lds, stream, a);
+    return ldt_check_launch("gemm_bf16_nt_mid(qkv+attention)");
+}
+
+bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a_in, int tokens, int head_dim, bool folded, hipStream_t stream, int* status) {
+    static const bool on = !(getenv("LDT_QKV_ATTN") && atoi(getenv("LDT_QKV_ATTN")) == 0);
+    if (!on || !mid_env() || tokens != 32 || head_dim != 64 || !a_in->attn_o) return false;
+    const GemmArgs& g = *a_in;
+    if (g.N % 192 != 0 || (g.N / 3) % 64 != 0 || g.M % 128 != 0 || g.K % MID_BK != 0 || g.K / MID_BK < MidCfg<128, 192>::NS + 2) return false;
+    if (folded && (g.stats_parts > 32 || g.stats_parts * 32 != g.K || !g.stats_in || !g.fold_S || !g.fold_C)) return false;
+    if (!ldt_aligned16(g.attn_o) || (g.bias && !ldt_aligned16(g.bias)) || g.ldx % 8 != 0 || g.ldw % 8 != 0) return false;
+    GemmArgs a = g;
+    a.col_major = 1;
+    *status = folded ? mid_qkv_attn_launch<MID_FOLD_CONSUMER>(a, stream) : mid_qkv_attn_launch<MID_FOLD_NONE>(a, stream);
     return true;
 }

@@ -30,6 +30,9 @@ struct GemmArgs {
     int dbg;                            // tools/dbg only (LDT_DBG_EPI bits: 1 no residual read, 2 no fp32 store, 4 no xs store, 8 no statistics)
     int max_wgs;                        // 256-tile kernel: cap on the persistent grid (0 = one workgroup per CU); sub-batch streams use 128
     int col_major;                      // v1 kernel: tile order (set by the launcher; see gemm_bf16_nt_kernel)
+    // ---- QKV projection + self-attention in one launch (gemm_mid.hip, 32-token samples, head dim 64): N = 3 * hidden columns [q | k | v];
+    // the kernel writes O[B][H][32][64] (the reference's raw (B,N,C) buffer, model/layers.py:190-197) to attn_o and NOT the q | k | v rows
+    bf16_t* attn_o; float attn_scale_log2e;
 };
 
 struct LnArgs {
@@ -73,7 +76,8 @@ struct SgemmArgs {
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
 int ldt_gemm_mid_shape(int epi, const GemmArgs* a);                // gemm_mid.hip: (BM << 16) | BN of the mid-size tile kernel for this problem, 0 = not taken
 int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream);
-bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
+bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);
+bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);   // fused QKV + attention (32 tokens, Dh 64); false = not taken   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
 bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // every GEMM of a Score block on the v1 kernels: statistics per 32 columns
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
