@@ -40,14 +40,15 @@
 
 // BM x BN output tile: 128 x 256 (the widest a CU's LDS and the accumulator budget take), 128 x 192 (bf16-output epilogues only: QKV with
 // N = 3 x 1024 over 2k rows is exactly 256 such tiles), 128 x 128, and 64 x 128 for the N = hidden residual GEMMs of a 2k-row batch
-// (256 workgroups instead of 128; the smaller stage buys a 4-deep ring)
+// (256 workgroups instead of 128; the smaller stage buys a 4-deep ring), 64 x 64 for the same GEMMs of a 1k-row batch (BASELINE configs[4]'s
+// per-GPU share: again 256 workgroups; 6-deep ring)
 template <int BM, int BN>
 struct MidCfg {
     static constexpr int MT = BM / 16;                   // 16-row accumulator tiles per compute wave (a wave spans all BM rows)
-    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (a wave = BN / 4 columns: 4 | 3 | 2 tiles)
+    static constexpr int NT = BN / 64;                   // 16-column accumulator tiles per compute wave (a wave = BN / 4 columns: 4 | 3 | 2 | 1 tiles)
     static constexpr int XB = BM * MID_BK * 2;           // X part of a stage (bytes)
     static constexpr int STAGE = XB + BN * MID_BK * 2;
-    static constexpr int NS = BM == 64 ? 4 : 3;          // ring stages
+    static constexpr int NS = BM == 64 ? (BN == 64 ? 6 : 4) : 3;   // ring stages
     static constexpr int RING = NS * STAGE;
     static constexpr int LDS = RING + 4 * 4096;
     static constexpr int XPW = BM / 8 / 4;               // X pieces per loader wave and K-tile
@@ -227,7 +228,9 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
         // K-tile kt+1 landed: the K-tiles issued after it are kt+2 .. min(kt + NS - 1, nkt - 1) (kt + NS goes out past the barrier)
         const int last = kt + C::NS - 1 < nkt - 1 ? kt + C::NS - 1 : nkt - 1;
         const int ahead = last - (kt + 1);               // 0 .. NS - 2
-        if (ahead >= 2) mid_wait_vmcnt<2 * C::PPW>();
+        if (C::NS >= 6 && ahead >= 4) mid_wait_vmcnt<(C::NS >= 6 ? 4 : 0) * C::PPW>();
+        else if (C::NS >= 5 && ahead == 3) mid_wait_vmcnt<(C::NS >= 5 ? 3 : 0) * C::PPW>();
+        else if (ahead >= 2) mid_wait_vmcnt<2 * C::PPW>();
         else if (ahead == 1) mid_wait_vmcnt<C::PPW>();
         else mid_wait_vmcnt<0>();
         MID_STAMP(5 + 3 * kt);
@@ -252,7 +255,7 @@ __device__ __forceinline__ f32x4 mid_resid_load(const GemmArgs& a, int m0, int n
     return *reinterpret_cast<const f32x4*>(a.resid + row * a.ldr + nb + (lane % CPR) * 4);
 }
 
-// `rpre` (EPI_RESID_F32, BN = 128): the wave's whole residual tile, requested before the main loop (2 x 16 B per lane and 16-row pass)
+// `rpre` (EPI_RESID_F32, BN <= 128): the wave's whole residual tile, requested before the main loop (NT x 16 B per lane and 16-row pass)
 // sum over the 8 lanes of an aligned lane octet (all 8 end up with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
 __device__ __forceinline__ float mid_oct_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -263,7 +266,7 @@ __device__ __forceinline__ float mid_oct_sum(float v) {
 
 template <int EPI, int BM, int BN, int FOLD>
 __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[MidCfg<BM, BN>::NT][MidCfg<BM, BN>::MT], int m0, int nb, int wn, int lane,
-                                             char* reg, const char* stage_base, const f32x4 (&rpre)[MidCfg<BM, BN>::MT][2], int step) {
+                                             char* reg, const char* stage_base, const f32x4 (&rpre)[MidCfg<BM, BN>::MT][MidCfg<BM, BN>::NT <= 2 ? MidCfg<BM, BN>::NT : 1], int step) {
     constexpr int NT = MidCfg<BM, BN>::NT, MT = MidCfg<BM, BN>::MT;
     const int lrow = lane & 15, lchk = lane >> 4;
     f32x4 bias4[NT];
@@ -273,7 +276,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmArgs& a, f32x4 (&acc)[Mid
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
         constexpr int RS = NT * 32 + 16;                 // staged row: NT*16 bf16 + 16 B pad
         constexpr int CHK = NT * 2;                      // 16-B chunks per row (8 | 6 | 4)
-        constexpr int CPR = NT == 2 ? 4 : 8;             // lanes per row (a power of two; NT = 3: lanes 6, 7 of each octet idle)
+        constexpr int CPR = NT <= 2 ? 4 : 8;             // lanes per row (a power of two; NT = 3: lanes 6, 7 of each octet idle, NT = 1: lanes 2, 3 of each quad)
         constexpr int RPI = 64 / CPR;                    // rows per store instruction (8 | 16)
         f32x4 s4[NT];
         if constexpr (FOLD == MID_FOLD_CONSUMER) {       // this wave's columns of the S | C slices the loader waves left in the staging tails
@@ -566,12 +569,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     // BN = 128 residual epilogue: the wave's whole residual tile (BM rows x 32 columns fp32: 2 x 16 B per lane and 16-row pass) is requested
     // here and arrives under the main loop.  NOT before the barrier: a CU's memory pipeline is a FIFO — requested first, these
     // 32-64 KB of (HBM / Infinity-Cache) misses held the loaders' first K-tiles back by 2-4 us (profiles/r04_mid_stamps.txt).
-    f32x4 rpre[MT][2];
-    if constexpr (EPI == EPI_RESID_F32 && NT == 2) {
+    f32x4 rpre[MT][NT <= 2 ? NT : 1];
+    if constexpr (EPI == EPI_RESID_F32 && NT <= 2) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) rpre[mi][it] = mid_resid_load<NT>(a, m0, n0 + wn * (BN / 4), lane, mi, it);
+            for (int it = 0; it < NT; ++it) rpre[mi][it] = mid_resid_load<NT>(a, m0, n0 + wn * (BN / 4), lane, mi, it);
     }
 
     if constexpr (BM == 128 && NT >= 3) {
@@ -630,25 +633,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
         mid_interleave<4, 2, 4 * NT>();
         mm(wb, xb, 1);
     } else if constexpr (BM == 64) {
-        // 64 x 128 tile: a wave owns 64 rows x 32 columns (2 x 4 accumulator tiles), a K-tile is ONE block of 16 MFMAs; the whole next K-tile's
-        // fragments (4 W + 8 X) are read into the other register set while this one is multiplied.  The reads of K-tile kt are complete
+        // 64 x 128 | 64 x 64 tile: a wave owns 64 rows x 32 | 16 columns (NT x 4 accumulator tiles), a K-tile is ONE block of 16 | 8 MFMAs; the
+        // whole next K-tile's fragments (2 NT W + 8 X) are read into the other register set while this one is multiplied.  The reads of K-tile kt are complete
         // before its MFMAs start, so the barrier that admits K-tile kt+1 also frees K-tile kt's stage.
-        bf16x8 wa[2][2], xa[2][4], wb[2][2], xb[2][4];
-        auto ld = [&](bf16x8 (&w)[2][2], bf16x8 (&x)[2][4], const char* st) {
+        bf16x8 wa[2][NT], xa[2][4], wb[2][NT], xb[2][4];
+        auto ld = [&](bf16x8 (&w)[2][NT], bf16x8 (&x)[2][4], const char* st) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { w[0][i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048); w[1][i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048); }
+            for (int i = 0; i < NT; ++i) { w[0][i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048); w[1][i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048); }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { x[0][i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048); x[1][i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048); }
         };
-        auto mm = [&](const bf16x8 (&w)[2][2], const bf16x8 (&x)[2][4]) {
+        auto mm = [&](const bf16x8 (&w)[2][NT], const bf16x8 (&x)[2][4]) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[h][ni], x[h][mi], acc[ni][mi], 0, 0, 0);
         };
+        constexpr int KT_MFMA = 8 * NT, KT_RD = (2 * NT + 8) < KT_MFMA ? (2 * NT + 8) : KT_MFMA;   // MFMAs / interleaved reads per K-tile
         int slot = 0;
         auto next_stage = [&]() { slot = slot + 1 == C::NS ? 0 : slot + 1; return smem_mid + slot * C::STAGE; };
         ld(wa, xa, smem_mid);
@@ -659,19 +663,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
             MID_BARRIER();                               // barrier kt: K-tile kt+1 landed (and K-tile kt's stage is free: its reads returned before this trip)
             ld(wb, xb, next_stage());
             mm(wa, xa);
-            mid_interleave<12, 1>();
+            mid_interleave<KT_RD, 1, KT_MFMA>();
             MID_LGKM0();
             MID_BARRIER();                               // barrier kt+1
             ld(wa, xa, next_stage());
             mm(wb, xb);
-            mid_interleave<12, 1>();
+            mid_interleave<KT_RD, 1, KT_MFMA>();
             MID_LGKM0();
         }
         if (kt + 1 < nkt) {
             MID_BARRIER();
             ld(wb, xb, next_stage());
             mm(wa, xa);
-            mid_interleave<12, 1>();
+            mid_interleave<KT_RD, 1, KT_MFMA>();
             mm(wb, xb);
         } else mm(wa, xa);
     } else {
@@ -750,16 +754,17 @@ int ldt_gemm_mid_shape(int epi, const GemmArgs* a) {
     const int mode = mid_env();                          // 0 off, 1 automatic; tools/dbg: 256 / 192 / 128 / 64 pin 128x256 / 128x192 / 128x128 / 64x128
     if (!mode) return 0;
     if (!(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32)) return 0;
-    if (a->K % MID_BK != 0 || a->N % 128 != 0 || a->M < 64 || a->ldo % 8 != 0) return 0;
+    if (a->K % MID_BK != 0 || a->N % 64 != 0 || a->M < 64 || a->ldo % 8 != 0) return 0;
     if (epi == EPI_RESID_F32 && (a->ldr % 4 != 0 || (a->gate && a->gate_sample_stride % 4 != 0))) return 0;
-    struct { int bm, bn; } cand[4] = {{128, 256}, {128, 192}, {128, 128}, {64, 128}};
+    struct { int bm, bn; } cand[5] = {{128, 256}, {128, 192}, {128, 128}, {64, 128}, {64, 64}};
     const bool bf16_out = epi == EPI_BF16 || epi == EPI_GELU_BF16;
     if (mode == 256) return a->N % 256 == 0 ? (128 << 16) | 256 : 0;
     if (mode == 128) return (128 << 16) | 128;
     if (mode == 64) return (64 << 16) | 128;
+    if (mode == 6464) return (64 << 16) | 64;
     long best_cost = 0; int best = 0;
     if (mode == 192) return (a->N % 192 == 0 && bf16_out) ? (128 << 16) | 192 : 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (a->N % cand[i].bn != 0 || (cand[i].bn == 192 && !bf16_out)) continue;
         const long wgs = (long)((a->M + cand[i].bm - 1) / cand[i].bm) * (a->N / cand[i].bn);
         if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) continue;
@@ -785,7 +790,7 @@ int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t strea
     const int bm = shape >> 16, bn = shape & 0xffff;
     if (bn == 192) return epi == EPI_BF16 ? mid_launch_t<EPI_BF16, 128, 192>(a, stream) : mid_launch_t<EPI_GELU_BF16, 128, 192>(a, stream);
 #define MID_CASE(E)                                                                                            \
-    case E: return bm == 64 ? mid_launch_t<E, 64, 128>(a, stream) : bn == 256 ? mid_launch_t<E, 128, 256>(a, stream) \
+    case E: return bm == 64 ? (bn == 64 ? mid_launch_t<E, 64, 64>(a, stream) : mid_launch_t<E, 64, 128>(a, stream)) : bn == 256 ? mid_launch_t<E, 128, 256>(a, stream) \
                                                                                : mid_launch_t<E, 128, 128>(a, stream)
     switch (epi) {
         MID_CASE(EPI_F32);

@@ -75,7 +75,9 @@ def test_gemm_all_epilogues(M, N, K):
                                    # 64 x 128 tiles (4-stage ring, K-tile-deep register double buffering): 1..5 K-tiles, ragged rows
                                    (2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (2048, 1024, 320), (1000, 1024, 448),
                                    # 128 x 192 tiles (bf16-output epilogues; the fp32 ones of these shapes take another form)
-                                   (2048, 3072, 64), (2048, 3072, 192), (1990, 3072, 320)])
+                                   (2048, 3072, 64), (2048, 3072, 192), (1990, 3072, 320),
+                                   # 64 x 64 tiles (6-stage ring): fewer K-tiles than stages, exactly as many, more; ragged rows
+                                   (1024, 1024, 64), (1024, 1024, 128), (1024, 1024, 384), (1024, 1024, 448), (1000, 1024, 704)])
 def test_gemm_mid_kernel(M, N, K):
     """The mid-size tile kernel (csrc/gemm_mid.hip: 128 x 256 / 128 x 128 / 64 x 128 tiles, loader waves, 3- / 4-stage ring) on the shapes the launcher hands
     it — incl. 1 / 2 / 3 / 5 K-tiles (prologue and drain paths of the ring), a ragged last row tile, a step-indexed shared gate, a per-sample
