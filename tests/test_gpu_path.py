@@ -172,11 +172,48 @@ def test_trainer_sample_trained_weights_fixed_bars(tiny_cfg, use_graph):
     worst = max(rel_mse(score(a["step_x"][j].cuda(), a["step_t"][j].cuda()).cpu(), a["step_params"][j]) for j in range(a["step_x"].shape[0]))
     assert worst < TOL_PARAMS, worst                                     # teacher-forced, the reference's own trajectory
     B = a["x0"].shape[0]
-    pts, eps = tr.sample(B, x0=a["x0"], noise=a["noises"], use_graph=use_graph)
+    traj = []
+    pts, eps = tr.sample(B, x0=a["x0"], noise=a["noises"], use_graph=use_graph, trajectory=traj)
     e_lat, e_pts = rel_mse(eps.cpu(), a["eps"]), rel_mse(pts.cpu(), a["points"])
     cd = O.chamfer_cd(pts.cpu(), a["points"]) / (a["points"] ** 2).sum(-1).mean(1)
     print("trained-tiny end to end: latents %.2e points %.2e chamfer/r2 %.2e" % (e_lat, e_pts, float(cd.max())))
     assert e_lat < 1e-4 and e_pts < 1e-3 and float(cd.max()) < 1e-3, (e_lat, e_pts, float(cd.max()))
+    # Why the latents sit at 7e-5 when every other latent comparison of the suite is at 2-4e-6: this fixture's schedule (N = 50:
+    # betas up to 0.4, and a last denoising step that multiplies the Score output by beta / std(1e-6) = 6) carries a Score-output error of
+    # relative MSE d to ~2 d in the final latents when it is independent from step to step, ~5-8 d when it is systematic — and ANY bf16-weight
+    # path has a systematic d ~ 1e-5 here.  Measured on the fp32 oracle itself: the same trajectory with nothing but the GEMM weights rounded
+    # to bf16 once (AdaLN / time MLP left in fp32, activations in fp32).  The GPU path must stay within 4x that at the end and at every step.
+    sens = _oracle_bf16_weight_sensitivity(O, tiny_cfg, sds, a)
+    xs = traj[0].cpu()
+    curve = [rel_mse(xs[i], sens["rec"][i]) for i in range(xs.shape[0])]
+    ratio = max(c / max(s_, 1e-7) for c, s_ in zip(curve, sens["curve"]))
+    print("  oracle under bf16-rounded GEMM weights: final latents %.2e (GPU / that = %.2f), per-step max %.2e; GPU per-step max %.2e, worst per-step ratio %.2f"
+          % (sens["final"], e_lat / sens["final"], max(sens["curve"]), max(curve), ratio))
+    assert e_lat <= 4 * sens["final"], (e_lat, sens["final"])
+    assert all(c <= 4 * max(s_, 1e-6) for c, s_ in zip(curve, sens["curve"])), (curve, sens["curve"])
+
+
+_SENS_CACHE = {}
+
+
+def _oracle_bf16_weight_sensitivity(O, cfg, sds, a):
+    """The fp32 oracle's own trajectory on the trained-tiny fixture with the Score's GEMM weights (ln_in, fc_q / fc_kv / fc_o, mlp fc / out,
+    ln_out.ln: what the product keeps as bf16 MFMA panels) rounded to bf16 once: {"final": rel-MSE of the final latents, "curve": per step,
+    "rec": the unperturbed per-step states}.  CPU, a few seconds; cached per session."""
+    if "v" in _SENS_CACHE:
+        return _SENS_CACHE["v"]
+    sd = sds["w"]
+    is_w = lambda k: k.endswith("weight") and "adaLN" not in k and any(t in k for t in ("fc_q", "fc_kv", "fc_o", "mlp.fc", "mlp.out", "ln_in", "ln_out.ln"))
+    sdq = {k: (v.to(torch.bfloat16).float() if is_w(k) else v) for k, v in sd.items()}
+    assert sum(is_w(k) for k in sd) == 2 + 5 * cfg.score.num_blocks          # ln_in, ln_out.ln + (fc_q, fc_kv, fc_o, mlp.fc, mlp.out) per block
+    nl = [a["noises"][i] for i in range(a["noises"].shape[0])]
+    with torch.no_grad():
+        rec, recq = [], []
+        _, eps = O.trainer_sample(sd, sds["c"], cfg, a["x0"], nl, record=rec)
+        _, epsq = O.trainer_sample(sdq, sds["c"], cfg, a["x0"], nl, record=recq)
+    assert rel_mse(eps, a["eps"]) < 1e-10                                # the oracle reproduces the reference's capture
+    _SENS_CACHE["v"] = {"final": rel_mse(epsq, eps), "curve": [rel_mse(recq[i][3], rec[i][3]) for i in range(len(rec))], "rec": [r[3] for r in rec]}
+    return _SENS_CACHE["v"]
 
 
 def test_free_running_per_step_curve(env):
