@@ -217,8 +217,7 @@ def roofline_pass(trainer, cfg, B, reps=3):
         kernels[name] = k
         # rocprofv3 symbol: <epilogue id, LN folding (1 producer, 2 consumer), residual rows through the operand ring (one tile per workgroup)>
         xr = 1 if name in ("gemm_o", "gemm_dn") and (M // 256) * (D // 256) <= 256 and M % 256 == 0 else 0
-        # (v3 = the full-line operand stream, default since round 3: LDT_GEMM_FL=0 selects v2 `gemm_bf16_nt_256_kernel`)
-        kname = "gemm_bf16_nt_256f_kernel" if int(os.environ.get("LDT_GEMM_FL", "1")) and M % 256 == 0 else "gemm_bf16_nt_256_kernel"
+        kname = "gemm_bf16_nt_256f_kernel"               # the 256-tile persistent kernel (full-line operand stream)
         sym = ("%s<%d, %d, %d>" % (kname, epi_id[name], fold_id[name] if folded else 0, xr)) if name in epi_id else \
             {"attention": "attn_fwd_head_kernel<64>" if 128 < T <= 256 and not os.environ.get("LDT_ATTN_FORCE") else "attn_fwd_kernel<64, false>",
              "ln_modulate": "ln_mod_vec_kernel<4, false>"}.get(name)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 17
+#define LDT_ABI_VERSION 18
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -314,6 +314,11 @@ typedef struct ldt_score_plan {
        probe forward before and after the loop (ldt_amd/diffusion.py) and leaves it NULL inside the loop. */
     float* fold_monitor;
 } ldt_score_plan;
+
+/* Which LN-folded route ldt_score_forward takes for a batch of M = batch*tokens rows (hidden D, mlp_hidden F, gemm_wgs as in the plan) when the plan
+ * offers `fold` tables: 0 = none (LayerNorm kernels), 1 = the 256-tile kernels (statistics per 256 columns), 2 = the mid-size tile kernels of small
+ * batches (statistics per 32 columns).  The host (Score.can_fold) asks before it builds the tables. */
+int ldt_score_lnfold_route(int32_t M, int32_t D, int32_t F, int32_t gemm_wgs);
 
 /* eps_out[M][z_dim] = Score(x[M][z_dim]) with the AdaLN row selected by *step_ptr (NULL = row 0). */
 int ldt_score_forward(const ldt_score_plan* plan, const float* x, float* eps_out,

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -50,6 +50,7 @@ SIGNATURES = {
     "ldt_gemm_resid_lnstats": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _i64,
                                _i32, _i32, _i32, _i32, _vp],
     "ldt_gemm_lnfold": [_i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "ldt_score_lnfold_route": [_i32, _i32, _i32, _i32],
     "ldt_layernorm_modulate": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
     "ldt_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ldt_attention_oproj_resid": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp],

@@ -236,6 +236,13 @@ extern "C" int ldt_emd_approx(const float* x, const float* y, int32_t S, int32_t
 }
 
 // ------------------------------------------------------------------------------ Score forward
+extern "C" int ldt_score_lnfold_route(int32_t M, int32_t D, int32_t F, int32_t gemm_wgs) {
+    if (M <= 0 || D <= 0 || F <= 0 || D % 256 != 0 || D > 1024 || F % 256 != 0) return 0;
+    if (ldt_gemm_lnfold_v1_route(M, D, F, gemm_wgs)) return 2;
+    const int lim = (gemm_wgs > 0 && gemm_wgs < LDT_NUM_CUS) ? gemm_wgs : LDT_NUM_CUS;
+    return (M % 256 == 0 && (long)(M / 256) * (D / 256) * 8 >= (long)lim * 5) ? 1 : 0;
+}
+
 static int check_plan(const ldt_score_plan* p) {
     LDT_REQUIRE(p, LDT_EARG, "score: null plan");
     LDT_REQUIRE(p->blocks > 0 && p->blocks <= LDT_MAX_BLOCKS, LDT_ESHAPE, "score: blocks=%d out of range", p->blocks);

@@ -57,13 +57,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, long ld
 // NW = 8 (512 threads, waves 4 x 2 over the tile): the mid-size form — a 256 x 128 tile with a 3-stage ring is ONE workgroup per CU
 // whose operand stream carries 85 flop per byte (128 x 64 tiles: 43), for the batches whose GEMMs are bound by the per-CU
 // L2 -> LDS rate (M = 1-4 k rows; DESIGN.md §4 "small-batch regime").
-// FOLD (small batches: every GEMM of a Score block on this kernel, Score.can_fold / ldt_gemm_lnfold_v1_route): the LN-folding
-// forms of the 256-tile kernel below with the row statistics kept per 32 output columns — a wave's half of a 64-wide tile —
-//   FOLD_PRODUCER (EPI_RESID_F32, TBN = 64, M % TBM == 0): also stores xs = bf16(x_new (1 + ln_scale)) and the wave's per-row
-//     (sum, sum of squares) over its 32 columns -> stats_out[n / 32][M][2] (cross-lane adds in a fixed order, no atomics);
-//   FOLD_CONSUMER (EPI_BF16 / EPI_GELU_BF16): X = xs; the tile's rows' K/32 partials are summed in part order under the first
-//     operand round trip (thread r < TBM: row r) into (rstd, -mean rstd) in LDS; the epilogue is y = rstd acc + (-mean rstd S + C).
-template <int EPI, int TBM, int TBN, int NST = 2, int NW = 4, int FOLD = FOLD_NONE>
+template <int EPI, int TBM, int TBN, int NST = 2, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a) {
     constexpr int BM = TBM, BN = TBN;
     constexpr int XB = TBM * BK * 2, WB = TBN * BK * 2;               // operand tile bytes per stage
@@ -71,8 +65,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
     constexpr int MT = TBM / (16 * WGM), NT = TBN / 32;               // 16x16 accumulator tiles per wave (m, n)
     constexpr int OPS = (TBM + TBN) / (8 * NW);                       // LDS-DMA instructions per wave and stage
     __shared__ __attribute__((aligned(16))) char smem[NST * (XB + WB)];  // [stage][X|W]
-    __shared__ float fold_rs[FOLD == FOLD_CONSUMER ? TBM * 2 : 2];       // (rstd, -mean rstd) of the tile's rows
-    __shared__ __attribute__((aligned(16))) float fold_sc[FOLD == FOLD_CONSUMER ? 2 * TBN : 4];   // this tile's slices of fold_S | fold_C
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,49 +103,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
             stage_tile<TBN, NW>(Wk, a.ldw, n0, a.N, st * BK, smem + st * (XB + WB) + XB, wave, lane);
             ++ahead;
         }
-    if (FOLD == FOLD_CONSUMER) {
-        // row statistics of this tile's rows, in flight together with the first operand stages (VMEM retires in order: the wait
-        // the compiler places before the arithmetic below also covers those stages — one round trip in all)
-        // 256 / TBM threads per row, each takes a contiguous run of the <= 32 partials: all of a thread's loads are issued before the
-        // first add (an in-order loop would be one memory round trip per partial), then run, then threads, are added in index order
-        constexpr int TPR = NW * 64 / TBM, PPT = 32 / TPR;
-        {
-            int row = m0 + tid / TPR;
-            row = row < a.M ? row : a.M - 1;
-            const int p0 = (tid % TPR) * PPT;
-            const float* sp = a.stats_in + (long)row * 2;
-            f32x2 t[PPT];
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) t[i] = (p0 + i < a.stats_parts) ? *reinterpret_cast<const f32x2*>(sp + (long)(p0 + i) * a.M * 2) : (f32x2){0.f, 0.f};
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) { s1 += t[i][0]; s2 += t[i][1]; }
-#pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) {                       // partner threads are adjacent lanes: lower run + upper run
-                const float o1 = __shfl_xor(s1, o, 64), o2 = __shfl_xor(s2, o, 64);
-                s1 = (tid & o) ? o1 + s1 : s1 + o1;
-                s2 = (tid & o) ? o2 + s2 : s2 + o2;
-            }
-            // the tile's S | C slices are step-indexed, hence cold in every cache at every step: fetched here, inside the prologue's one
-            // round trip, so that the epilogue opens on LDS reads (the 256-tile kernel rides its mid-loop DMA slot for the same reason)
-            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f};
-            const int scn = (tid & (TBN / 4 - 1)) * 4;
-            const bool sc_lane = tid < 2 * (TBN / 4) && n0 + scn < a.N;
-            if (sc_lane) {
-                const long fst = a.step_ptr ? (long)(*a.step_ptr) * a.fold_step_stride : 0L;
-                sc4 = *reinterpret_cast<const f32x4*>((tid < TBN / 4 ? a.fold_S : a.fold_C) + fst + n0 + scn);
-            }
-            if (tid < 2 * (TBN / 4)) *reinterpret_cast<f32x4*>(&fold_sc[(tid < TBN / 4 ? 0 : TBN) + scn]) = sc4;
-            if (tid % TPR == 0) {
-                const float invk = 1.0f / (float)a.K;
-                const float mean = s1 * invk;
-                const float var = fmaxf(s2 * invk - mean * mean, 0.f);
-                const float r = rsqrtf(var + 1e-6f);
-                fold_rs[(tid / TPR) * 2] = r; fold_rs[(tid / TPR) * 2 + 1] = -mean * r;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    } else if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+    if (NST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
     else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -202,16 +152,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
     // ---- epilogue: lane holds D[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)], r = 0..3 ----
     const float* gate = a.gate;
     if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
-    const long fstep = (FOLD != FOLD_NONE && a.step_ptr) ? (long)(*a.step_ptr) : 0L;
-    const float* lsc = FOLD == FOLD_PRODUCER ? a.ln_scale + fstep * a.ln_step_stride : nullptr;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
         const int m = m0 + wm * (TBM / WGM) + mi * 16 + lrow;
         if (m >= a.M) continue;
         const float* grow = nullptr;
         if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
-        float rr = 1.f, nm = 0.f, s1 = 0.f, s2 = 0.f;
-        if (FOLD == FOLD_CONSUMER) { rr = fold_rs[(m - m0) * 2]; nm = fold_rs[(m - m0) * 2 + 1]; }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int n = n0 + wn * (TBN / 2) + ni * 16 + lchk * 4;
@@ -223,14 +169,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                 if (full) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + n); b[0] = t[0]; b[1] = t[1]; b[2] = t[2]; b[3] = t[3]; }
                 else for (int r = 0; r < 4; ++r) if (n + r < a.N) b[r] = a.bias[n + r];
             }
-            if (FOLD == FOLD_CONSUMER) {                            // y = rstd acc + (-mean rstd S + C): the bias is inside C (N % 64 == 0 here)
-                const f32x4 S4 = *reinterpret_cast<const f32x4*>(&fold_sc[n - n0]), C4 = *reinterpret_cast<const f32x4*>(&fold_sc[TBN + n - n0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rr * v[r] + (nm * S4[r] + C4[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r];
-            }
+            for (int r = 0; r < 4; ++r) v[r] += b[r];
             if (EPI == EPI_F32) {
                 float* o = reinterpret_cast<float*>(a.out) + (long)m * a.ldo + n;
                 if (full) *reinterpret_cast<f32x4*>(o) = v;
@@ -248,14 +188,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                         for (int r = 0; r < 4; ++r) x[r] = x[r] + v[r];
                     }
                     *reinterpret_cast<f32x4*>(o) = x;
-                    if (FOLD == FOLD_PRODUCER) {
-                        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(lsc + n);
-                        const bf16x4 pk = {(bf16_t)(x[0] * (1.f + sc4[0])), (bf16_t)(x[1] * (1.f + sc4[1])), (bf16_t)(x[2] * (1.f + sc4[2])),
-                                           (bf16_t)(x[3] * (1.f + sc4[3]))};
-                        *reinterpret_cast<bf16x4*>(a.xs + (long)m * a.ldxs + n) = pk;
-                        s1 += (x[0] + x[1]) + (x[2] + x[3]);
-                        s2 += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
-                    }
                 } else {
                     for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = rs[r] + (grow ? grow[n + r] : 1.f) * v[r];
                 }
@@ -281,12 +213,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
                     *reinterpret_cast<bf16x4*>(o) = pk;
                 } else for (int r = 0; r < 4; ++r) if (n + r < a.N) o[r] = (bf16_t)v[r];
             }
-        }
-        if (FOLD == FOLD_PRODUCER) {                                // the four lanes of a row (lchk = 0..3), fixed order; whole tiles only
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lchk == 0)
-                *reinterpret_cast<f32x2*>(a.stats_out + ((long)((n0 + wn * (TBN / 2)) / (TBN / 2)) * a.M + m) * 2) = (f32x2){s1, s2};
         }
     }
 }
@@ -320,71 +246,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_nt_kernel(const GemmArgs a)
 #define V2_RING_BYTES (4 * V2_STAGE_BYTES)
 #define V2_LDS_BYTES (V2_RING_BYTES + 8 * 4096)
 
-__device__ __forceinline__ int v2_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
-
-// Per-lane DMA source pointers of one operand stream: 2 pieces (16 rows x 64 B each) per wave and sub-tile.
-struct V2Stream {
-    const bf16_t* p[2];     // this lane's 16-B source of piece 0 / 1 at the stream's current (tile, sub-tile)
-    int it, v, inc;         // tile iteration; sub-tiles left in that tile; elements per advance (0 once parked)
-};
-__device__ __forceinline__ void v2_stream_seek(V2Stream& st, const bf16_t* __restrict__ g, long ld, int row0, int nrows_total,
-                                               int k0, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = (wave * 2 + q) * 16 + (lane >> 2);
-        const int csrc = (lane & 3) ^ v2_swz(r);
-        int grow = row0 + r;
-        grow = grow < nrows_total ? grow : nrows_total - 1;   // clamp: rows past the edge are never stored
-        st.p[q] = g + (long)grow * ld + k0 + csrc * 8;
-    }
-}
-__device__ __forceinline__ void v2_stream_issue(const V2Stream& st, char* lds_oper, int wave) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)st.p[q],
-                                         (__attribute__((address_space(3))) void*)(lds_oper + (wave * 2 + q) * 1024), 16, 0, 0);
-}
-
 #define V2_BARRIER()                          \
     do {                                      \
         __builtin_amdgcn_sched_barrier(0);    \
         __builtin_amdgcn_s_barrier();         \
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
-
-// generic (edge-safe) epilogue straight from the fragment layout: lane holds D[n = nb + lchk*4 + r][m = mb + lrow]
-template <int EPI>
-__device__ __forceinline__ void v2_epilogue_edge(const GemmArgs& a, f32x4 (&acc)[4][8], int m0, int n0, int grp, int wn,
-                                                 int lrow, int lchk, const float* gate) {
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + grp * 128 + mi * 16 + lrow;
-        if (m >= a.M) continue;
-        const float* grow = nullptr;
-        if (EPI == EPI_RESID_F32 && gate) grow = gate + (long)(m / a.rows_per_sample) * a.gate_sample_stride;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + lchk * 4;
-            if (n >= a.N) continue;
-            f32x4 v = acc[ni][mi];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r >= a.N) continue;
-                float y = v[r] + (a.bias ? a.bias[n + r] : 0.f);
-                const long oi = (long)m * a.ldo + n + r;
-                if (EPI == EPI_F32) reinterpret_cast<float*>(a.out)[oi] = y;
-                else if (EPI == EPI_RESID_F32)
-                    reinterpret_cast<float*>(a.out)[oi] = a.resid[(long)m * a.ldr + n + r] + (grow ? grow[n + r] : 1.f) * y;
-                else if (EPI == EPI_DISCARD) { if (a.M < 0) reinterpret_cast<float*>(a.out)[oi] = y; }
-                else {
-                    if (EPI == EPI_GELU_BF16) y = gelu_erf_fast(y);
-                    if (EPI == EPI_RELU_BF16) { if (a.skip) y += (float)a.skip[(long)m * a.lds_ + n + r]; y = fmaxf(y, 0.f); }
-                    reinterpret_cast<bf16_t*>(a.out)[oi] = (bf16_t)y;
-                }
-            }
-        }
-    }
-}
 
 // sum over the 16 lanes of a DPP row (all 16 end up with the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
 __device__ __forceinline__ float row16_sum(float v) {
@@ -571,7 +438,7 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = x[r] + g4[r] * v[r];
                 }
-                if ((EPI != EPI_DISCARD || a.M < 0) && (XRING || !(a.dbg & 2))) *reinterpret_cast<f32x4*>(o) = v;
+                if (XRING || !(a.dbg & 2)) *reinterpret_cast<f32x4*>(o) = v;
                 if (FOLD == FOLD_PRODUCER) {
                     const bf16x4 pk = {(bf16_t)(v[0] * sc4[0]), (bf16_t)(v[1] * sc4[1]), (bf16_t)(v[2] * sc4[2]), (bf16_t)(v[3] * sc4[3])};
                     if (XRING || !(a.dbg & 4)) *reinterpret_cast<bf16x4*>(a.xs + (mrow0 + row) * a.ldxs + nb + ch * 4) = pk;
@@ -606,226 +473,6 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
     }
 }
 
-// XRING = 1 (EPI_RESID_F32, one tile per workgroup — launcher): the epilogue fetches the fp32 residual rows through the idle
-// operand ring (v2_epilogue_staged).
-template <int EPI, int FOLD = FOLD_NONE, int XRING = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;
-    const int lrow = lane & 15, lchk = lane >> 4;
-    const int nks = a.K >> 5;
-
-    // ---- this workgroup's tile list: the tiles are cut into 8 contiguous chunks (one per XCD label bid&7, so the
-    //      X row-panels an XCD's CUs share stay in its L2); inside a chunk workgroup j takes tiles j, j+wpx, ...
-    const int tiles_n = (a.N + 255) / 256;
-    const int tiles = ((a.M + 255) / 256) * tiles_n;
-    const int G = gridDim.x, bid = blockIdx.x;
-    const int nx = G < 8 ? G : 8;                                        // XCD labels in use
-    const int xcd = bid % nx, j = bid / nx;
-    const int wpx = (G - xcd + nx - 1) / nx;                             // workgroups carrying this label
-    const int c_lo = (int)((long)tiles * xcd / nx), c_hi = (int)((long)tiles * (xcd + 1) / nx);
-    const int my_tiles = (c_hi - c_lo - j + wpx - 1) / wpx > 0 ? (c_hi - c_lo - j + wpx - 1) / wpx : 0;
-    if (my_tiles == 0) return;                                           // whole workgroup, before any barrier
-
-    // Tile order: GROUPED — `gm` row panels are swept column by column before the next `gm` rows, so the tiles an XCD's
-    // 32 workgroups hold at any time form a (gm rows x 32/gm columns) block: gm X panels + 32/gm W panels are live in
-    // its 4 MiB L2 instead of 2 + 16 (row-major order at 16 column tiles).
-    const int tiles_m = (a.M + 255) / 256, gm = a.group_m;
-    auto tile_of = [&](int it, int& m0, int& n0) {
-        const int id = c_lo + j + it * wpx;
-        if (gm <= 1) { m0 = (id / tiles_n) * 256; n0 = (id % tiles_n) * 256; return; }
-        const int per = gm * tiles_n, g = id / per, r = id - g * per;
-        const int rows = min(gm, tiles_m - g * gm);
-        m0 = (g * gm + r % rows) * 256; n0 = (r / rows) * 256;
-    };
-    // Advance a stream by one sub-tile (called right after the MFMAs of a phase are issued): the common path is two
-    // pointer bumps.  At the end of this workgroup's stream it parks (inc = 0): later batches re-read the last
-    // sub-tile (valid memory), are counted by vmcnt like any other and are never consumed.
-    // (bump first, in place; the tile switch then overwrites the pointers: written this way the common path is straight-
-    //  line code with one NOT-taken branch — the "if (likely) { bump; return; }" form compiled to a taken branch plus two
-    //  64-bit register copies in every load segment)
-    auto next_x = [&](V2Stream& st) {
-        st.p[0] += st.inc; st.p[1] += st.inc;
-        const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
-        st.v = left;
-        if (__builtin_expect(left == 0, 0)) {                            // once per tile
-            const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
-            st.it = it;
-            if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.X, a.ldx, m0, a.M, 0, wave, lane); st.v = nks; }
-            else { st.p[0] -= st.inc; st.p[1] -= st.inc; st.v = 0x40000000; st.inc = 0; }
-        }
-    };
-    auto next_w = [&](V2Stream& st) {
-        st.p[0] += st.inc; st.p[1] += st.inc;
-        const int left = __builtin_amdgcn_readfirstlane(st.v) - 1;
-        st.v = left;
-        if (__builtin_expect(left == 0, 0)) {
-            const int it = __builtin_amdgcn_readfirstlane(st.it) + 1;
-            st.it = it;
-            if (it < my_tiles) { int m0, n0; tile_of(it, m0, n0); v2_stream_seek(st, a.W, a.ldw, n0, a.N, 0, wave, lane); st.v = nks; }
-            else { st.p[0] -= st.inc; st.p[1] -= st.inc; st.v = 0x40000000; st.inc = 0; }
-        }
-    };
-
-    V2Stream sx{{nullptr, nullptr}, 0, nks, 32}, sw{{nullptr, nullptr}, 0, nks, 32};
-    {
-        int m0, n0;
-        tile_of(0, m0, n0);
-        v2_stream_seek(sx, a.X, a.ldx, m0, a.M, 0, wave, lane);
-        v2_stream_seek(sw, a.W, a.ldw, n0, a.N, 0, wave, lane);
-    }
-    // step-indexed (cache-cold) epilogue vectors of the FIRST tile, fetched ahead of everything else
-    const float* gate = a.gate;
-    if (EPI == EPI_RESID_F32 && gate && a.step_ptr) gate += (long)(*a.step_ptr) * a.gate_step_stride;
-    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
-    const float* ln_scale = (FOLD == FOLD_PRODUCER) ? a.ln_scale + (long)step * a.ln_step_stride : nullptr;
-    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
-    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
-    f32x4 g4_pre = {1.f, 1.f, 1.f, 1.f}, sc4_pre = {0.f, 0.f, 0.f, 0.f};
-    const bool pre_ok = (EPI == EPI_RESID_F32) && gate && a.gate_sample_stride == 0;
-    if (EPI == EPI_RESID_F32) {
-        int m0, n0;
-        tile_of(0, m0, n0);
-        if (n0 + 256 <= a.N) {
-            if (pre_ok) g4_pre = *reinterpret_cast<const f32x4*>(gate + n0 + wn * 64 + (lane & 15) * 4);
-            if (FOLD == FOLD_PRODUCER) sc4_pre = *reinterpret_cast<const f32x4*>(ln_scale + n0 + wn * 64 + (lane & 15) * 4);
-        }
-    }
-    int gx = 0, gw = 0;                                                  // stream positions of the next X / W batch
-#define ISSUE_X() do { v2_stream_issue(sx, smem2 + (gx & 3) * V2_STAGE_BYTES, wave); ++gx; } while (0)
-#define ISSUE_W() do { v2_stream_issue(sw, smem2 + (gw & 3) * V2_STAGE_BYTES + V2_OPER_BYTES, wave); ++gw; } while (0)
-
-    ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx); ISSUE_W(); next_w(sw); ISSUE_X(); next_x(sx);   // X0 W0 X1 W1 X2
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     // sub-tile 0 landed
-    V2_BARRIER();
-    if (EPI == EPI_RESID_F32)                                            // (older than every DMA above: already retired)
-        asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
-
-    // per-lane LDS read offsets inside a ring slot: row*64 + ((chunk ^ f(row)) << 4)
-    int xoff[8], woff[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const int r = grp * 128 + i * 16 + lrow; xoff[i] = r * 64 + ((lchk ^ v2_swz(r)) << 4); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + lrow; woff[i] = V2_OPER_BYTES + r * 64 + ((lchk ^ v2_swz(r)) << 4); }
-
-    // stores a wave leaves in flight after one STAGED epilogue (its loads are consumed, hence retired, inside it);
-    // a smaller count only waits longer (FOLD_PRODUCER: 32 x + 32 xs + 1 stats stores exceed the 6-bit counter)
-    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
-                             : (FOLD == FOLD_PRODUCER) ? 57 : 32;
-    const bool aligned = (a.ldo % 8 == 0) && (EPI != EPI_RESID_F32 || a.ldr % 4 == 0) && (EPI != EPI_RELU_BF16 || !a.skip || a.lds_ % 4 == 0);
-    char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
-
-    int g = 0;                                                           // stream position being consumed
-    bool prev_staged = false;
-    for (int it = 0; it < my_tiles; ++it) {
-        int m0, n0;
-        tile_of(it, m0, n0);
-        f32x4 acc[4][8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
-
-        // One 32-deep sub-tile = two phases.  The load segment is the loop's critical resource (it is longer than the
-        // partner's 16-MFMA segment): three TAKEN skip-branches per sub-tile around rarely executed blocks cost 8-11 % of
-        // the whole GEMM (measured), while the not-taken tile-switch branch of next_x / next_w is free (a branch-free
-        // bump/seek form measured equal).  So the once-per-tile extras of FOLD_CONSUMER are separate instantiations of
-        // the body (ST_* flags) placed at fixed sub-tile positions, not runtime tests inside one loop body.
-        enum { ST_PLAIN = 0, ST_FIRST = 1 /* first wait allows for the previous epilogue's stores */, ST_CHECK_FIRST = 2 /* runtime v == 0 */,
-               ST_FOLD_DMA = 4 /* fetch this tile's row statistics + S | C slices */, ST_FOLD_FINAL = 8 /* (rstd, -mean rstd) per row */ };
-        int v = 0;
-        auto subtile = [&](auto flags_c) {
-            constexpr int FL = decltype(flags_c)::value;
-            const char* st = smem2 + (g & 3) * V2_STAGE_BYTES;
-            bf16x8 wf[4], xf[4];
-            // ---------------- phase 0: W (4 n-tiles) + X (m-tiles 0..3); DMA: W of stream position g+2 ----------------
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + woff[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[i]);
-            ISSUE_W();
-            next_w(sw);
-            if (FL & ST_FOLD_DMA) {
-                // Row statistics of this tile: piece q = wave = part*2 + half -> 128 rows x 8 B, into the tail of this wave's
-                // staging area; S | C: four half-wave pieces.  Issued two sub-tiles into the tile (every wave is past the
-                // previous epilogue's reads: >= 8 barriers), retired by the counted wait of sub-tile 3, read from sub-tile 6 on.
-                if (wave < 2 * a.stats_parts) {
-                    const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
-                }
-                if (wave < 4 && lane < 32) {
-                    const float* src = (wave < 2 ? fold_S : fold_C) + n0 + (wave & 1) * 128 + lane * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_SC_OFF), 16, 0, 0);
-                }
-            }
-            if ((FL & ST_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
-            V2_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            V2_BARRIER();
-            // ---------------- phase 1: X (m-tiles 4..7); DMA: X of stream position g+3; counted wait ----------------
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xoff[4 + i]);
-            ISSUE_X();
-            next_x(sx);
-            // position g+1 has landed once all but the 3 newest batches (+ a preceding epilogue's stores) retired
-            // (an edge epilogue issues a data-dependent number of stores: fall back to the always-safe vmcnt(6))
-            if (((FL & ST_FIRST) || ((FL & ST_CHECK_FIRST) && v == 0)) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + EPI_VMEM) : "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            V2_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            V2_BARRIER();
-            ++g;
-        };
-#define SUBT(f) std::integral_constant<int, (f)>{}
-        if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 8 sub-tiles
-            subtile(SUBT(ST_FIRST)); subtile(SUBT(ST_PLAIN)); subtile(SUBT(ST_FOLD_DMA));
-            for (v = 3; v < 6; ++v) subtile(SUBT(ST_PLAIN));
-            subtile(SUBT(ST_FOLD_FINAL));
-            for (v = 7; v < nks; ++v) subtile(SUBT(ST_PLAIN));
-        } else {
-            for (v = 0; v < nks; ++v) subtile(SUBT(ST_CHECK_FIRST));
-        }
-#undef SUBT
-        if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
-
-        prev_staged = (m0 + 256 <= a.M) && (n0 + 256 <= a.N) && aligned;
-        if (XRING) {
-            // XRING kernel (one tile per workgroup: launcher): the residual rows arrive through the now idle operand ring —
-            // every wave's outstanding batches must have landed first, and every wave must be past its last ring read
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V2_BARRIER();
-            // (one tile per workgroup: the gate / ln_scale vectors fetched before the main loop are this tile's — no load may
-            //  follow the ring requests, hipcc would wait for it with vmcnt(0) and with it for all sixteen requests)
-            v2_epilogue_staged<EPI, FOLD, 1>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
-                                                true, g4_pre, sc4_pre, smem2 + wave * 16384);
-        } else if (prev_staged || FOLD != FOLD_NONE)                     // FOLD: the launcher admits interior, aligned tiles only
-            v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
-                                          it == 0 && (pre_ok || FOLD == FOLD_PRODUCER), g4_pre, sc4_pre);
-        else v2_epilogue_edge<EPI>(a, acc, m0, n0, grp, wn, lrow, lchk, gate);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail batches before exit
-#undef ISSUE_X
-#undef ISSUE_W
-}
-
 // =================================================================================================
 // v3 ("full-line"): the same 8-wave ping-pong 256x256 kernel with the operand stream rebuilt around WHOLE 128-B LINES.
 //
@@ -845,9 +492,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256_kernel(const GemmArgs a)
 //   * Operand addresses: a wave-uniform base (SGPRs: tile origin + k) + per-lane 32-bit offsets that never change (8 VGPRs), so the
 //     stream advance is scalar.  Interior tiles only (M, N multiples of 256: the launcher falls back to v2 otherwise).
 // Tile order, epilogues (staged / LN-fold producer + consumer / XRING) and persistence are v2's.
-#ifndef LDT_GEMM_FL_DEFAULT
-#define LDT_GEMM_FL_DEFAULT 1          /* v3 measured 4-10 % faster per GEMM, -3.2 % per SDE step (round 3, tools/dbg/env_ab.py LDT_GEMM_FL) */
-#endif
 #ifndef V3_PREISSUE
 #define V3_PREISSUE 1                   /* request a tile's second K-tile before the previous tile's epilogue stores */
 #endif
@@ -979,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
     const int xb0 = xrb + ((lchk ^ sw) << 4), xb1 = xrb + (((4 + lchk) ^ sw) << 4);
     const int wb0 = wrb + ((lchk ^ sw) << 4), wb1 = wrb + (((4 + lchk) ^ sw) << 4);
 
-    constexpr int EPI_VMEM = (EPI == EPI_DISCARD) ? 0 : (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
+    constexpr int EPI_VMEM = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) ? 16
                              : (FOLD == FOLD_PRODUCER) ? 57 : 32;
     char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
     bool prev_staged = false;
@@ -1134,6 +778,14 @@ extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LD
 static std::atomic<int> g_dbg_epi{-1};
 extern "C" int ldt_dbg_gemm_epi(int32_t bits) { g_dbg_epi.store(bits); return LDT_OK; }   // tools/dbg/epi_ablate.py
 
+// The 256-tile kernel takes interior, aligned tiles only (M, N multiples of 256, K a multiple of 64 with >= 2 K-tiles, 16-byte rows);
+// everything else belongs to the mid-size / small-tile kernels.
+static bool gemm256_takes(int epi, const GemmArgs* a) {
+    return a->K % 64 == 0 && a->K >= 128 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 &&
+           (epi != EPI_RESID_F32 || (a->ldr % 4 == 0 && (!a->gate || a->gate_sample_stride % 4 == 0))) &&
+           (epi != EPI_RELU_BF16 || !a->skip || a->lds_ % 4 == 0);
+}
+
 template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     // Tile order: wide outputs (QKV: 12 column tiles, MLP-up: 16) are swept in groups of 8 row panels, so an XCD's 32
@@ -1143,52 +795,35 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;
     const int gm_dbg = g_group_m.load();
     GemmArgs a_copy = *a_in;
-    const int tn = (a_in->N + 255) / 256, tm = (a_in->M + 255) / 256;
+    const int tn = a_in->N / 256, tm = a_in->M / 256;
     a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
     // residual rows of a one-tile workgroup through the operand ring (v2_epilogue_staged XRING, kernel <.., .., 1>): needs the exact VMEM op
     // count of the epilogue (no per-sample gate loads, no debug skips) and 16-B aligned rows.  LDT_RESID_RING=0: A/B runs.
     static const bool xring_on = !(getenv("LDT_RESID_RING") && atoi(getenv("LDT_RESID_RING")) == 0);
-    const bool xring = (EPI == EPI_RESID_F32 && xring_on && a_in->resid && a_in->ldr % 4 == 0 && ldt_aligned16(a_in->resid) &&
-                        (!a_in->gate || a_in->gate_sample_stride == 0) && a_in->M % 256 == 0 && a_in->N % 256 == 0 && a_in->ldo % 8 == 0);
+    const bool xring = (EPI == EPI_RESID_F32 && xring_on && a_in->resid && ldt_aligned16(a_in->resid) && (!a_in->gate || a_in->gate_sample_stride == 0));
     static const int dbg_env = getenv("LDT_DBG_EPI") ? atoi(getenv("LDT_DBG_EPI")) : 0;
     a_copy.dbg = g_dbg_epi.load() >= 0 ? g_dbg_epi.load() : dbg_env;
     const GemmArgs* a = &a_copy;
-    LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256");
-    const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    LDT_REQUIRE(gemm256_takes(EPI, a), LDT_ESHAPE, "gemm256: M=%d N=%d must be multiples of 256, K=%d of 64 (>= 128), rows 16-byte aligned", a->M, a->N, a->K);
+    const int tiles = tm * tn;
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;
     const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
-    // v3 (full-line operand stream, 64-deep K-tiles): interior + aligned tiles only.  LDT_GEMM_FL=0 keeps v2 everywhere (A/B runs).
-    static const int fl_env = getenv("LDT_GEMM_FL") ? atoi(getenv("LDT_GEMM_FL")) : LDT_GEMM_FL_DEFAULT;
-    const bool fl = fl_env && EPI != EPI_DISCARD && a->dbg == 0 && a->K % 64 == 0 && a->K >= 128 && a->M % 256 == 0 && a->N % 256 == 0 && a->ldo % 8 == 0 &&
-                    (EPI != EPI_RESID_F32 || (a->ldr % 4 == 0 && (!a->gate || a->gate_sample_stride % 4 == 0))) &&
-                    (EPI != EPI_RELU_BF16 || !a->skip || a->lds_ % 4 == 0);
     if constexpr (EPI == EPI_RESID_F32) {
         if (xring && grid == tiles && a->dbg == 0) {                     // every workgroup has exactly one tile: the ring is idle in its epilogue
-            if (fl) {
-                LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256f");
-                hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
-                return ldt_check_launch("gemm_bf16_nt_256f");
-            }
-            LDT_ENSURE_LDS((&gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256");
-            hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
-            return ldt_check_launch("gemm_bf16_nt_256");
-        }
-    }
-    if constexpr (EPI != EPI_DISCARD) {
-        if (fl) {
-            LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256f");
-            hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+            LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256f");
+            hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
             return ldt_check_launch("gemm_bf16_nt_256f");
         }
     }
-    hipLaunchKernelGGL((gemm_bf16_nt_256_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
-    return ldt_check_launch("gemm_bf16_nt_256");
+    LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256f");
+    hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+    return ldt_check_launch("gemm_bf16_nt_256f");
 }
 
-// LN-folding launches: always the 256-tile kernel, interior + aligned tiles only (checked here, assumed by the kernel).
-// All four GEMMs of a Score block (N = D, 3D, F) fall to the v1 kernels under ldt_gemm_launch's 5/8 rule: the batches whose LN folding
-// runs in the v1 FOLD forms (statistics per 32 columns: stats[D / 32][M][2]).  M % 128 == 0: whole tiles (the producer's row sums).
+// LN-folding launches.  Large batches: the 256-tile kernel (statistics per 256 columns).  Small batches — all four GEMMs of a Score block
+// (N = D, 3D, F) below ldt_gemm_launch's 5/8 rule — fold through the mid-size tile kernel (gemm_mid.hip, statistics per 32 columns:
+// stats[D / 32][M][2]) when it takes every one of them in a folded form; otherwise the LayerNorm kernels run.
 static int gemm_variant_env() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("LDT_GEMM_FORCE"); v = e ? atoi(e) : 0; }
@@ -1197,27 +832,14 @@ static int gemm_variant_env() {
 bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs) {
     const int lim = (max_wgs > 0 && max_wgs < LDT_NUM_CUS) ? max_wgs : LDT_NUM_CUS;
     auto small = [&](int N) { return (long)((M + 255) / 256) * ((N + 255) / 256) * 8 < (long)lim * 5; };
-    return gemm_variant_env() == 0 && M % 128 == 0 && D % 64 == 0 && F % 64 == 0 && small(D) && small(3 * D) && small(F);
-}
-
-// v1 FOLD forms: TBN = 64 tiles (the statistics granule is a wave's 32-column half), 128 x 64 when that still gives every CU two tiles
-template <int EPI, int FOLD>
-static int launch_v1_fold(const GemmArgs* a, hipStream_t stream) {
-    auto ntiles = [&](int bm, int bn) { return (long)(a->M / bm) * (a->N / bn); };
-    GemmArgs b = *a;
-    const bool big = FOLD == FOLD_CONSUMER && a->N % 128 == 0 && ntiles(128, 128) >= 2 * LDT_NUM_CUS;   // (consumers only: the producer's granule is a 32-column half tile)
-    const bool wide = ntiles(128, 64) >= 2 * LDT_NUM_CUS;
-    const long tm = a->M / (wide || big ? 128 : 64), tn = a->N / (big ? 128 : 64);
-    b.col_major = tn >= 3 * tm ? 1 : 0;
-    if (big) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 128, 128, 2, 4, FOLD == FOLD_CONSUMER ? FOLD_CONSUMER : FOLD_NONE>), dim3((unsigned)ntiles(128, 128)), dim3(256), 0, stream, b);
-    else if (wide) hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 128, 64, 2, 4, FOLD>), dim3((unsigned)ntiles(128, 64)), dim3(256), 0, stream, b);
-    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, 64, 64, 3, 4, FOLD>), dim3((unsigned)ntiles(64, 64)), dim3(256), 0, stream, b);
-    return ldt_check_launch("gemm_bf16_nt(fold)");
+    if (!(gemm_variant_env() == 0 && M % 128 == 0 && D % 64 == 0 && F % 64 == 0 && D <= 1024 && small(D) && small(3 * D) && small(F))) return false;
+    return ldt_gemm_mid_lnfold_takes(EPI_RESID_F32, M, D, D) && ldt_gemm_mid_lnfold_takes(EPI_RESID_F32, M, D, F) &&
+           ldt_gemm_mid_lnfold_takes(EPI_BF16, M, 3 * D, D) && ldt_gemm_mid_lnfold_takes(EPI_GELU_BF16, M, F, D);
 }
 
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     // route: stats_parts says which statistics layout the caller's buffers use — K / 256 (N / 256 for the producer) parts: the 256-tile
-    // kernel; K / 32 (N / 32): the v1 kernel (ldt_gemm_lnfold_v1_route)
+    // kernel; K / 32 (N / 32): the mid-size tile kernel (ldt_gemm_lnfold_v1_route)
     const int width = epi == EPI_RESID_F32 ? a->N : a->K;
     const bool v1 = a->stats_parts > 0 && a->stats_parts * 32 == width && a->stats_parts * 256 != width;
     if (v1) LDT_REQUIRE(a->M > 0 && a->M % 128 == 0 && a->N % 64 == 0 && a->K >= 128 && a->K % BK == 0, LDT_ESHAPE,
@@ -1237,8 +859,9 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
                     "gemm_lnfold: producer needs xs / ln_scale / stats_out (16-byte aligned)");
         if (v1) {
             int st = LDT_OK;
-            if (gemm_variant_env() == 0 && ldt_gemm_mid_lnfold_try(EPI_RESID_F32, a, stream, &st)) return st;   // mid-size tile kernel (gemm_mid.hip)
-            return launch_v1_fold<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
+            if (ldt_gemm_mid_lnfold_try(EPI_RESID_F32, a, stream, &st)) return st;   // mid-size tile kernel (gemm_mid.hip)
+            ldt_set_error("gemm_lnfold: statistics per 32 columns are the mid-size tile kernel's; it does not take M=%d N=%d K=%d as a producer", a->M, a->N, a->K);
+            return LDT_ESHAPE;
         }
         return launch_256<EPI_RESID_F32, FOLD_PRODUCER>(a, stream);
     }
@@ -1248,8 +871,9 @@ int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     if (v1) {
         LDT_REQUIRE(a->stats_parts <= 32, LDT_ESHAPE, "gemm_lnfold (v1 route): K=%d > 1024 input channels", a->K);
         int st = LDT_OK;
-        if (gemm_variant_env() == 0 && ldt_gemm_mid_lnfold_try(epi, a, stream, &st)) return st;
-        return epi == EPI_BF16 ? launch_v1_fold<EPI_BF16, FOLD_CONSUMER>(a, stream) : launch_v1_fold<EPI_GELU_BF16, FOLD_CONSUMER>(a, stream);
+        if (ldt_gemm_mid_lnfold_try(epi, a, stream, &st)) return st;
+        ldt_set_error("gemm_lnfold: statistics per 32 columns are the mid-size tile kernel's; it does not take M=%d N=%d K=%d as a consumer", a->M, a->N, a->K);
+        return LDT_ESHAPE;
     }
     LDT_REQUIRE(a->stats_parts >= 1 && a->stats_parts <= 4 && a->stats_parts * 256 == a->K, LDT_EARG,
                 "gemm_lnfold: consumer needs stats_in[K/256 <= 4][M][2] (or [K/32][M][2] for the small-batch kernels); K=%d parts=%d", a->K, a->stats_parts);
@@ -1291,14 +915,13 @@ int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream) {
     const int lim256 = (a->max_wgs > 0 && a->max_wgs < LDT_NUM_CUS) ? a->max_wgs : LDT_NUM_CUS;
     // (N <= 128 — the Compressor's 128-channel convs over millions of point rows — would leave half of every 256-wide tile
     //  empty: the 128^2 kernel streams those 5.7 % faster end to end, tools/dbg/c4_chunks.py)
-    if ((force == 256 || (force == 0 && tiles256 * 8 >= lim256 * 5 && a->N > 128)) && a->M >= 16 && a->N >= 16) {
+    if ((force == 256 || (force == 0 && tiles256 * 8 >= lim256 * 5 && a->N > 128)) && gemm256_takes(epi, a)) {
         switch (epi) {
             case EPI_F32: return launch_256<EPI_F32>(a, stream);
             case EPI_BF16: return launch_256<EPI_BF16>(a, stream);
             case EPI_GELU_BF16: return launch_256<EPI_GELU_BF16>(a, stream);
             case EPI_RELU_BF16: return launch_256<EPI_RELU_BF16>(a, stream);
             case EPI_RESID_F32: return launch_256<EPI_RESID_F32>(a, stream);
-            case EPI_DISCARD: return launch_256<EPI_DISCARD>(a, stream);   // timing-only (tools/dbg): no stores
             default: ldt_set_error("gemm: unknown epilogue %d", epi); return LDT_EARG;
         }
     }

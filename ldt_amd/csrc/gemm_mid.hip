@@ -750,7 +750,12 @@ static int mid_env() {
 
 // Tile shape for (M, N): this path is bound by what a CU can take in through the L2 -> LDS DMA (~80 GB/s, profiles/r04_mid_stamps.txt), so
 // the cost of a shape is rounds x bytes per workgroup and K-tile ~ ceil(workgroups / 256) x (BM + BN).  -> (BM << 16) | BN, 0 = not taken.
-int ldt_gemm_mid_shape(int epi, const GemmArgs* a) {
+// fold: 0 = any form; 1 = LN-folded producer (a wave's 32 columns are the statistics granule: BN = 128 forms only);
+//       2 = LN-folded consumer (the loader waves' statistics pass: 128-row forms only)
+static int mid_shape_for(int epi, const GemmArgs* a, int fold);
+int ldt_gemm_mid_shape(int epi, const GemmArgs* a) { return mid_shape_for(epi, a, 0); }
+
+static int mid_shape_for(int epi, const GemmArgs* a, int fold) {
     const int mode = mid_env();                          // 0 off, 1 automatic; tools/dbg: 256 / 192 / 128 / 64 pin 128x256 / 128x192 / 128x128 / 64x128
     if (!mode) return 0;
     if (!(epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32)) return 0;
@@ -758,14 +763,17 @@ int ldt_gemm_mid_shape(int epi, const GemmArgs* a) {
     if (epi == EPI_RESID_F32 && (a->ldr % 4 != 0 || (a->gate && a->gate_sample_stride % 4 != 0))) return 0;
     struct { int bm, bn; } cand[5] = {{128, 256}, {128, 192}, {128, 128}, {64, 128}, {64, 64}};
     const bool bf16_out = epi == EPI_BF16 || epi == EPI_GELU_BF16;
+    if (fold == 0) {
     if (mode == 256) return a->N % 256 == 0 ? (128 << 16) | 256 : 0;
     if (mode == 128) return (128 << 16) | 128;
     if (mode == 64) return (64 << 16) | 128;
     if (mode == 6464) return (64 << 16) | 64;
+    }
     long best_cost = 0; int best = 0;
     if (mode == 192) return (a->N % 192 == 0 && bf16_out) ? (128 << 16) | 192 : 0;
     for (int i = 0; i < 5; ++i) {
         if (a->N % cand[i].bn != 0 || (cand[i].bn == 192 && !bf16_out)) continue;
+        if ((fold == 1 && cand[i].bn != 128) || (fold == 2 && cand[i].bm != 128)) continue;
         const long wgs = (long)((a->M + cand[i].bm - 1) / cand[i].bm) * (a->N / cand[i].bn);
         if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) continue;
         const long cost = ((wgs + LDT_NUM_CUS - 1) / LDT_NUM_CUS) * (cand[i].bm + cand[i].bn);
@@ -813,9 +821,20 @@ static int mid_fold_launch_t(const GemmArgs& a, hipStream_t stream) {
     return ldt_check_launch("gemm_bf16_nt_mid(fold)");
 }
 
+// would the folded form of this GEMM (M x N x K, statistics per 32 columns) be taken?  (Score.can_fold / ldt_gemm_lnfold_v1_route)
+bool ldt_gemm_mid_lnfold_takes(int epi, int M, int N, int K) {
+    if (!mid_env()) return false;
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.ldo = N; g.ldr = N;
+    const int shape = mid_shape_for(epi, &g, epi == EPI_RESID_F32 ? 1 : 2);
+    if (!shape) return false;
+    if (epi == EPI_RESID_F32) return N % 32 == 0;
+    return K % 32 == 0 && K / 32 <= 32 && K / MID_BK >= MidCfg<128, 256>::NS + 2;
+}
+
 bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a_in, hipStream_t stream, int* status) {
     if (!mid_env()) return false;
-    const int shape = ldt_gemm_mid_shape(epi, a_in);
+    const int shape = mid_shape_for(epi, a_in, epi == EPI_RESID_F32 ? 1 : 2);
     if (!shape) return false;
     const int bm = shape >> 16, bn = shape & 0xffff;
     GemmArgs a = *a_in;

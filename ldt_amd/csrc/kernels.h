@@ -2,8 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_F32 = 0, EPI_BF16 = 1, EPI_GELU_BF16 = 2, EPI_RELU_BF16 = 3, EPI_RESID_F32 = 4,
-       EPI_DISCARD = 5 /* timing-only: main loop without output stores (tools/dbg) */ };
+enum { EPI_F32 = 0, EPI_BF16 = 1, EPI_GELU_BF16 = 2, EPI_RELU_BF16 = 3, EPI_RESID_F32 = 4 };
 #define LDT_NUM_CUS 256      // MI355X
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GELU = 3 };
 
@@ -76,9 +75,10 @@ struct SgemmArgs {
 int ldt_gemm_launch(int epi, const GemmArgs* a, hipStream_t stream);
 int ldt_gemm_mid_shape(int epi, const GemmArgs* a);                // gemm_mid.hip: (BM << 16) | BN of the mid-size tile kernel for this problem, 0 = not taken
 int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream);
+bool ldt_gemm_mid_lnfold_takes(int epi, int M, int N, int K);       // would the LN-folded form (statistics per 32 columns) of this GEMM be taken?
 bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);
 bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);   // fused QKV + attention (32 tokens, Dh 64); false = not taken   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
-bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // every GEMM of a Score block on the v1 kernels: statistics per 32 columns
+bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // small batch: every GEMM of a Score block folds through the mid-size tile kernel (statistics per 32 columns)
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);

@@ -264,33 +264,25 @@ class Score(nn.Module):
         return c, mod
 
     def can_fold(self, B, T, gemm_wgs=0):
-        """LN folding pays when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs' tiles fill at
-        least 5/8 of the workgroups they may use (all 256 CUs, or a sub-batch stream's share `gemm_wgs`) — the same rule
-        by which ldt_gemm_launch prefers the 256^2 kernel; at M = 8192 on the whole chip the 128^2 kernel + LayerNorm
-        launches measured 3 % faster — or, for small batches (the shipped 32-token config: M = 2048), when EVERY GEMM of the
-        block runs the small-tile kernels, whose LN-folding forms keep the row statistics per 32 columns
-        (ldt_gemm_lnfold_v1_route in csrc/gemm_bf16.hip; this predicate mirrors it).
-        LDT_LN_FOLD=0 disables it, =2 forces it wherever the shapes allow (tests, A/B runs)."""
+        """LN folding pays (a) when every GEMM of the block runs whole 256x256 tiles and the residual GEMMs' tiles fill at least 5/8 of the
+        workgroups they may use (all 256 CUs, or a sub-batch stream's share `gemm_wgs`) — the rule by which ldt_gemm_launch prefers the 256^2
+        kernel; at M = 8192 on the whole chip the smaller tiles + LayerNorm launches measured 3 % faster — and (b) for small batches (the shipped
+        32-token config: M = 2048) when the mid-size tile kernels (csrc/gemm_mid.hip) take all four GEMMs of the block in their folded forms:
+        there the loader waves form the row statistics while the ring fills (98.5 -> 92.5 us per block, profiles/r04_t32_kernel_sequence*.txt).
+        The C++ forward makes the same decision (`ldt_score_lnfold_route`); this method asks it.
+        LDT_LN_FOLD=0 disables folding, =2 forces it wherever a route exists; LDT_LN_FOLD_SMALL=0 disables (b) only (A/B runs)."""
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
         F = self.Transformer[0].mlp.out.in_channels if not self.unet else 0
-        if self._fold_disabled and mode != 2:
+        if (self._fold_disabled and mode != 2) or mode == 0 or self.unet:
             return False
-        if mode == 0 or self.unet or D % 256 or D > 1024 or F % 256:
-            return False
-        lim = gemm_wgs if 0 < gemm_wgs < 256 else 256
-        t256 = lambda n: -(-M // 256) * -(-n // 256)
-        small = M % 128 == 0 and not int(os.environ.get("LDT_GEMM_FORCE", "0")) and all(t256(n) * 8 < lim * 5 for n in (D, 3 * D, F))
-        if small:
-            # On the mid-size tile kernels (csrc/gemm_mid.hip, default for these batches) the folded forms pay: the loader waves form the row
-            # statistics while the ring fills, so a consumer costs +1 us and a producer +2 us against two 5.8-us LayerNorm launches
-            # (shipped 32-token config, B = 64: 98.5 -> 92.5 us per block, profiles/r04_t32_kernel_sequence.txt).  On the round-3 small-tile
-            # kernels (LDT_GEMM_MID=0) it measured neutral (3.04 vs 3.05 ms per SDE step) and stays opt-in there.
-            dflt = "1" if int(os.environ.get("LDT_GEMM_MID", "1")) else "0"
-            return mode == 2 or bool(int(os.environ.get("LDT_LN_FOLD_SMALL", dflt)))
-        if M % 256:
-            return False
-        return mode == 2 or (M // 256) * (D // 256) * 8 >= lim * 5
+        route = int(lib().ldt_score_lnfold_route(M, D, F, gemm_wgs))
+        if route == 2:
+            return mode == 2 or bool(int(os.environ.get("LDT_LN_FOLD_SMALL", "1")))
+        if route == 1:
+            return True
+        # (mode 2 used to force the 256-tile route below the 5/8 rule: still possible when M is a multiple of 256 and no small route exists)
+        return mode == 2 and M % 256 == 0 and D % 256 == 0 and D <= 1024 and F % 256 == 0
 
     # The folded projections round x (1 + scale) to bf16 BEFORE the row mean is removed: their operand-rounding error is
     # (1 + mean^2 / variance) x the LayerNorm kernel's (tests/test_gpu_kernels.py::test_gemm_lnfold_error_law_vs_row_mean:
