@@ -502,14 +502,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
 // -------------------------------------------------------------------------------------------------
 // Whole-head form for the Score's self-attention at 129..256 tokens (Dh = 64: T = 256, the headline shape): one workgroup of EIGHT
 // waves per (b,h), every query row of the head in flight at once (wave w owns rows 32 w ..).  All of the head's K and V rows go to
-// LDS by LDS-DMA (1-KiB pieces, swizzle applied on the source address), the wave's Q fragments are requested right behind them, and
-// ONE wait covers the lot: a workgroup pays one memory round trip, then runs its four key tiles without a barrier, then stages its
-// output rows through the (now free) K region.  The streaming kernel pays a round trip per 64-key tile behind a barrier (its tile
+// LDS by LDS-DMA (1-KiB pieces, swizzle applied on the source address) behind the wave's Q fragments, requested tile by tile, and the
+// workgroup starts on key tile t as soon as ITS pieces are in (counted vmcnt + one barrier per tile, round 4): one memory round trip
+// per workgroup of which only the first tile's share is exposed; the output rows are staged through the (then free) K region.
+// The streaming kernel pays a round trip per 64-key tile behind a barrier (its tile
 // compute, ~0.8 us, is shorter than the load it is supposed to hide), the 4-wave resident kernel two register-staged load rounds
 // plus a Q round trip per query block.  64 KiB of LDS and <= 128 VGPRs: two workgroups (16 waves) per CU.  Same math, same layouts,
 // the tile is one online-softmax step (attn_tile_joint): results agree with the other two kernels to rounding, not bit for bit.
-template <int DH>
-__global__ __launch_bounds__(512, 2) void attn_fwd_head_kernel(const AttnArgs a, int ntl) {
+template <int DH, int NTL>   // NTL = 64-key tiles of the head (compile-time: every counted wait below is then straight-line code)
+__global__ __launch_bounds__(512, 4) void attn_fwd_head_kernel(const AttnArgs a) {
+    constexpr int ntl = NTL;
     constexpr int KT = 64;
     constexpr int ROWB = DH * 2;
     constexpr int CH = ROWB / 16;
@@ -528,59 +530,78 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_head_kernel(const AttnArgs a,
     const bf16_t* Qb = a.Q + (long)b * a.q_batch_stride + head * DH;
     const bf16_t* Kb = a.K + (long)b * a.kv_batch_stride + head * DH;
     const bf16_t* Vb = a.V + (long)b * a.kv_batch_stride + head * DH;
-    {
-        const int npieces = ntl * KT / RPP;
-        const int lr = lane / CH, cd = lane % CH;
-#ifdef ATT_DBG_NOLOAD
-        for (int p = wave; p < 0; p += 8) {
-#else
-        for (int p = wave; p < npieces; p += 8) {
-#endif
-            const int row = p * RPP + lr;
-            const int krow = row < a.Nk ? row : a.Nk - 1;               // rows past Nk: P is exactly 0 there
-            const int sk = (DH == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
-            const int sv = (DH == 64) ? (((row >> 1) & 1) << 2) : 0;
-            const bf16_t* ks = Kb + (long)krow * a.ldk + ((cd ^ sk) << 3);
-            const bf16_t* vs = Vb + (long)krow * a.ldv + ((cd ^ sv) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                             (__attribute__((address_space(3))) void*)(Ks + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                             (__attribute__((address_space(3))) void*)(Vs + p * 1024), 16, 0, 0);
-        }
-    }
     const int q0 = wave * 32;
     const bool active = q0 < a.Nq;                                      // wave-uniform
-    bf16x8 qf[NS];
-    if (active) {
+    // ---- tile-ordered landing: a wave's requests are, oldest first, its Q fragments (asm loads: hipcc drains the whole queue around a
+    //      register load it knows of when LDS-DMA is in flight beside it) and then (K, V) piece t * 8 + wave of tile t = 0, 1, ..  VMEM returns
+    //      in order, so "tile t is here" = at most 2 (ntl - 1 - t) younger requests outstanding + one barrier: tile t's 16 MFMAs + softmax
+    //      run while tiles t + 1.. are still on their way (one round trip per workgroup, but only the first tile's share of it exposed).
+    static_assert(DH == 64 && NTL >= 1 && NTL <= 4, "attn_fwd_head_kernel: built for head dim 64 (8 pieces per 64-key tile = one per wave), <= 256 keys");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 qi[NS];
+    {
         int qrow = q0 + r;
         qrow = qrow < a.Nq ? qrow : a.Nq - 1;
         const bf16_t* qp = Qb + (long)qrow * a.ldq + 8 * hh;
 #pragma unroll
+        for (int s = 0; s < NS; ++s) {
 #ifdef ATT_DBG_NOLOAD
-        for (int s = 0; s < NS; ++s) qf[s] = (bf16x8){(bf16_t)(float)lane, 1, 1, 1, 1, 1, 1, 1};
-        (void)qp;
+            qi[s] = (i32x4){lane, 1, 1, 1};
+            (void)qp;
 #else
-        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qi[s]) : "v"(qp + 16 * s) : "memory");
 #endif
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    {
+        const int lr = lane / CH, cd = lane % CH;
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)Ks;
+#ifdef ATT_DBG_NOLOAD
+        for (int t = 0; t < 0; ++t) {
+#else
+        for (int t = 0; t < ntl; ++t) {
+#endif
+            const int p = t * 8 + wave;
+            const int row = p * RPP + lr;
+            const int krow = row < a.Nk ? row : a.Nk - 1;               // rows past Nk: P is exactly 0 there
+            const int sk = (row >> 1) & 7;
+            const int sv = ((row >> 1) & 1) << 2;
+            const bf16_t* ks = Kb + (long)krow * a.ldk + ((cd ^ sk) << 3);
+            const bf16_t* vs = Vb + (long)krow * a.ldv + ((cd ^ sv) << 3);
+            // (asm, not the builtin: with LDS-DMA it knows of in flight hipcc puts vmcnt(0) in front of the first ds_read_b64_tr of V)
+            const unsigned kd = lds_base + p * 1024, vd = kd + ntl * TILE;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ks), "s"(kd) : "memory");   // (m0: hipcc keeps nothing there in this kernel — no builtin DMA, no movrel)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(vs), "s"(vd) : "memory");
+        }
+    }
+    // the Q registers become visible to the compiler only through this wait (tile 0's: 2 younger requests per later tile may be out)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qi[0]), "+v"(qi[1]), "+v"(qi[2]), "+v"(qi[3]) : "n"(2 * (NTL - 1)) : "memory");
     f32x16 oacc[ND];
     float m_run = -INFINITY, l_run = 0.f;
-    if (active) {
-        const float c = a.scale_log2e;
-        AttnLaneOffs<DH> lo;
-        lo.init(lane);
+    const float c = a.scale_log2e;
+    AttnLaneOffs<DH> lo;
+    lo.init(lane);
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+    bf16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = __builtin_bit_cast(bf16x8, qi[s]);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        if (t > 0) {
+            if (t == NTL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (t == NTL - 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                    // raw: __syncthreads() would drain vmcnt to 0 (the later tiles' pieces)
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef ATT_DBG_NOCOMPUTE
-        for (int t = 0; t < ntl; ++t) { l_run += (float)qf[t & (NS - 1)][0]; (void)c; }
+        l_run += (float)qf[t & (NS - 1)][0];
 #else
-        for (int t = 0; t < ntl; ++t)
-            attn_tile_joint<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+        if (active) attn_tile_joint<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
 #endif
     }
     __syncthreads();                                                    // every wave is done with K and V: their LDS becomes the output stage
@@ -748,14 +769,22 @@ static int launch_resident(const AttnArgs* a, hipStream_t s) {
     return ldt_check_launch("attn_fwd_resident");
 }
 
+template <int DH, int NTL>
+static int launch_head_t(const AttnArgs* a, hipStream_t s) {
+    size_t lds = (size_t)2 * NTL * 64 * DH * 2;
+    if (lds < (size_t)8 * 32 * DH * 2) lds = (size_t)8 * 32 * DH * 2;
+    LDT_ENSURE_LDS((&attn_fwd_head_kernel<DH, NTL>), 65536, "attention");
+    hipLaunchKernelGGL((attn_fwd_head_kernel<DH, NTL>), dim3((unsigned)(a->B * a->H)), dim3(512), lds, s, *a);
+    return ldt_check_launch("attn_fwd_head");
+}
 template <int DH>
 static int launch_head(const AttnArgs* a, hipStream_t s) {
-    const int ntl = (a->Nk + 63) / 64;
-    size_t lds = (size_t)2 * ntl * 64 * DH * 2;
-    if (lds < (size_t)8 * 32 * DH * 2) lds = (size_t)8 * 32 * DH * 2;
-    LDT_ENSURE_LDS(&attn_fwd_head_kernel<DH>, 65536, "attention");
-    hipLaunchKernelGGL(attn_fwd_head_kernel<DH>, dim3((unsigned)(a->B * a->H)), dim3(512), lds, s, *a, ntl);
-    return ldt_check_launch("attn_fwd_head");
+    switch ((a->Nk + 63) / 64) {
+        case 1: return launch_head_t<DH, 1>(a, s);
+        case 2: return launch_head_t<DH, 2>(a, s);
+        case 3: return launch_head_t<DH, 3>(a, s);
+        default: return launch_head_t<DH, 4>(a, s);                      // (caller: Nk <= 256)
+    }
 }
 
 int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s) {
