@@ -410,8 +410,8 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
                         const float* noise, long noise_step_stride, long elem_offset, uint64_t seed, int* step_counter,
                         const ldt_cond_args* cond, float* x_traj, hipStream_t s) {
     if (cond) {                                                 // per-sample AdaLN rows of this step
-        TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, step_counter, p->batch, cond->t_dim, s));
-        SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_SILU,
+        TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, step_counter, p->batch, cond->t_dim, 1, s));   // c_buf = silu(c)
+        SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_NONE,
                     LDT_ACT_NONE, p->batch, cond->n_mod, cond->t_dim};
         TRY(ldt_sgemm_launch(&g, s));
     }

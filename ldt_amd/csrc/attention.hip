@@ -179,9 +179,9 @@ __device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, 
                 oacc[d][i] = o[0]; oacc[d][i + 1] = o[1];
             }
     }
+    bf16x8 pf[4];
     const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
     f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
-    bf16x8 pf[4];
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
         const f32x2 ea = (f32x2){s0[i], s0[i + 1]} * c2 + nmc2;      // v_pk_fma_f32

@@ -7,7 +7,7 @@
 // 157 TFLOP/s (MI355X_MICROARCH.md), the rate of the fp32 VALU, but one instruction does the work of 64 v_fma and the
 // operands come from LDS once per 32x32 block instead of once per 4x4 register tile.
 //
-// Structure: 256 threads = 4 waves; WG tile TM x TN (128x128: waves 2x2 of 64x64; 32x256: waves 1x4 of 32x64 for the skinny
+// Structure: 256 threads = 4 waves; WG tile TM x TN (128x128: waves 2x2 of 64x64; 32x128: waves 1x4 of 32x32 for the skinny
 // per-step conditional AdaLN, M = batch), k-slabs of BK = 16 (32 for the skinny tile), operands staged global -> registers -> LDS
 // ([row][k], row stride BK + 4 floats: conflict-free 16-B reads), double-buffered in registers (the next k-slab's global loads are in flight during the
 // MFMAs).  Per 8 k's a lane reads ONE 16-B chunk per 32-row block: lanes 0-31 hold k 0..3, lanes 32-63 k 4..7 of that slab —
@@ -133,8 +133,15 @@ bool ldt_sgemm_mfma_try(const SgemmArgs* a, hipStream_t s, int* status) {
     if (a->K % 4 != 0 || a->K < 8 || a->lda % 4 != 0 || a->ldb % 4 != 0 || !ldt_aligned16(a->A) || !ldt_aligned16(a->B)) return false;
     if ((long)a->M * a->N < 64 * 64) return false;       // tiny problems: launch-bound either way, keep the simple kernel
     if (a->M <= 48) {                                     // skinny: per-step per-sample AdaLN rows (M = batch), weight streaming
-        dim3 grid((a->N + 255) / 256, (a->M + 31) / 32);
-        hipLaunchKernelGGL((sgemm_mfma_kernel<32, 256, 1, 4, 32>), grid, dim3(256), 0, s, *a);   // (215 -> 190 us at M = 32, N = 149,504; 128 x 64 slabs: equal)
+        // 32 x 128 tiles, 32-deep slabs: M = 32, N = 149,504, K = 1024 in 161 us = 3.8 TB/s of weights with the SiLU of the AdaLN input applied
+        // by the caller (176 with it in stage(); 32 x 256 tiles: 196; 16-deep slabs: 215).  Round-4 probes (tools/dbg/skinny_sgemm_bench.py,
+        // profiles/r04_skinny_sgemm_probes.txt): a second slab of register prefetch is SLOWER (200 us), rows padded off the 4-KiB stride 165-173,
+        // slab-contiguous weights 163-168; one workgroup per CU alone (N = 32,768) runs 1.5 us per slab and the time grows 35 us per further
+        // workgroup per CU; an LDS-DMA ring form of this tile (4 stages, counted vmcnt, one barrier per slab) ran 150-158 us stand-alone but
+        // 30 us SLOWER per step inside the sampling loop (two 80-KB workgroups per CU = 2.3 rounds with a tail; this kernel's 1168 workgroups
+        // are all resident) and was not kept.  A plain read stream of the same bytes gets 6.0 TB/s on the box; the fp32 MFMAs alone are 62 us.
+        dim3 grid((a->N + 127) / 128, (a->M + 31) / 32);
+        hipLaunchKernelGGL((sgemm_mfma_kernel<32, 128, 1, 4, 32>), grid, dim3(256), 0, s, *a);
     } else {
         dim3 grid((a->N + 127) / 128, (a->M + 127) / 128);
         if (grid.y >= 65536) return false;

@@ -302,6 +302,8 @@ def test_layernorm_modulate(M, C):
 # ------------------------------------------------------------------------------------------- fp32 linears
 @pytest.mark.parametrize("M,N,K", [(5, 64, 3), (300, 128, 20), (1000, 768, 64), (7, 2048, 1024), (65, 40, 128), (130, 300, 256),
                                    (32, 1000, 512), (1000, 2048, 1024), (4096, 40, 128), (2048, 128, 20),
+                                   # LDS-DMA streaming form of the skinny AdaLN-row GEMM (M <= 32, N >= 2048, K % 32 == 0): ragged N, M < 32
+                                   (19, 2085, 512), (32, 4224, 256), (1, 2048, 1024),
                                    # streaming forms (skinny_linear.hip): millions-of-rows convs of the Compressor, ragged tails
                                    (20001, 128, 3), (16385, 128, 20), (9000, 64, 32), (30003, 3, 128), (8193, 8, 64), (10000, 1, 512)])
 def test_sgemm(M, N, K):
