@@ -322,10 +322,17 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
         if (p->kv_cond[l]) {                                    // cross-attention: q from the modulated x, K|V from the condition
             const int S = p->cond_tokens;
             GemmArgs gq{BF(p->Hb), D, BF(p->w_q[l]), D, p->b_q[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, D, D};
-            gq.max_wgs = p->gemm_wgs; LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
+            gq.max_wgs = p->gemm_wgs;
+            gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
+            gq.attn_k = BF(p->kv_cond[l]); gq.attn_v = BF(p->kv_cond[l]) + D; gq.attn_ldkv = 2L * D; gq.attn_kv_batch_stride = (long)S * 2 * D;
+            int fst = LDT_OK;
+            if (ldt_gemm_mid_q_xattn_try(&gq, T, S, D / p->heads, s, &fst)) { TRY(fst); }   // 32 x 32 tokens: projection + attention in one launch
+            else {
+            LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->kv_cond[l]), 2L * D, (long)S * 2 * D, BF(p->kv_cond[l]) + D, 2L * D,
                         BFM(p->Ob), p->batch, p->heads, T, S, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
             LAUNCH(LDT_PROF_ATTN, ldt_attn_launch(&at, D / p->heads, s));
+            }
         } else {                                                // self-attention: fused q|k|v projection of the modulated x
             GemmArgs gq{BF(p->Hb), D, BF(p->w_qkv[l]), D, p->b_qkv[l], p->QKV, 3L * D, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, M, 3 * D, D};
             gq.max_wgs = p->gemm_wgs;

@@ -63,6 +63,8 @@ struct MidCfg {
 //     and its S | C slices behind the first ring fill, form (rstd, -mean rstd) per row and leave both in the tails of the staging areas; the
 //     compute waves' epilogue is y = rstd acc + (-mean rstd S + C).
 enum { MID_FOLD_NONE = 0, MID_FOLD_PRODUCER = 1, MID_FOLD_CONSUMER = 2 };
+enum { MID_ATTN_NONE = 0, MID_ATTN_SELF = 1 /* QKV projection + self-attention, 128 x 192 */, MID_ATTN_CROSS = 2 /* q projection + cross-attention, 64 x 64 */ };
+#define MID_XKV_BYTES 16384           /* cross-attention: [sample 2][K | V][32 keys][128 B] behind the staging areas */
 #define MID_TAIL_OFF 2304            /* bf16 staging uses at most 16 rows x 144 B of each compute wave's 4 KiB; the tails hold: */
 #define MID_RS_OFF (0 * 4096 + MID_TAIL_OFF)     /* (rstd, -mean rstd) of the tile's <= 128 rows (1 KiB)  */
 #define MID_S_OFF (1 * 4096 + MID_TAIL_OFF)      /* fold_S slice, BN floats (<= 1 KiB)                    */
@@ -113,7 +115,7 @@ extern "C" int ldt_dbg_mid_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 // ATTN (fused QKV + attention, BN = 192): tile column c of head h = tile_n is output column / W row (c / 64) * hidden + h * 64 + c % 64
 __device__ __forceinline__ int mid_attn_col(int c, int h, int hidden) { return (c >> 6) * hidden + h * 64 + (c & 63); }
 
-template <int BM, int BN, int FOLD, bool ATTN>
+template <int BM, int BN, int FOLD, int ATTN>
 __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw, int lane, int m0, int n0, int kbase, int nkt, int step) {
     using C = MidCfg<BM, BN>;
     // piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7).
@@ -129,11 +131,11 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
 #pragma unroll
     for (int q = 0; q < C::WPW; ++q) {
         const int r = (lw * C::WPW + q) * 8 + (lane >> 3);
-        const int rr = ATTN ? mid_attn_col(r, n0 / BN, a.N / 3) : (n0 + r < a.N ? r : a.N - 1 - n0);
+        const int rr = ATTN == MID_ATTN_SELF ? mid_attn_col(r, n0 / BN, a.N / 3) : (n0 + r < a.N ? r : a.N - 1 - n0);
         wo[q] = rr * (int)a.ldw * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
     }
     const char* xbase = reinterpret_cast<const char*>(a.X + (long)m0 * a.ldx + kbase);
-    const char* wbase = reinterpret_cast<const char*>(a.W + (ATTN ? 0L : (long)n0 * a.ldw) + kbase);
+    const char* wbase = reinterpret_cast<const char*>(a.W + (ATTN == MID_ATTN_SELF ? 0L : (long)n0 * a.ldw) + kbase);
     auto issue = [&](int slot) {                         // the K-tile the bases stand at -> stage `slot`; then advance one K-tile
         char* st = smem + slot * C::STAGE;
 #pragma unroll
@@ -148,6 +150,18 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
     };
     MID_STAMP_DECL();
     MID_STAMP(0);
+    if constexpr (ATTN == MID_ATTN_CROSS) {
+        // the K | V rows (32 condition tokens x 64 channels of head n0 / 64) of the tile's two samples: 16 pieces, 4 per loader wave, the OLDEST
+        // requests of the wave — every counted wait below covers them, the prologue barrier publishes them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = lw * 4 + q, sp = g >> 3, which = (g >> 2) & 1, row = (g & 3) * 8 + (lane >> 3);
+            const bf16_t* src = (which ? a.attn_v : a.attn_k) + (long)(m0 / 32 + sp) * a.attn_kv_batch_stride + (long)row * a.attn_ldkv + n0 +
+                                (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + C::LDS + g * 1024), 16, 0, 0);
+        }
+    }
     issue(0);
     if (nkt > 1) issue(1);
     MID_STAMP(1);
@@ -187,7 +201,7 @@ __device__ __forceinline__ void mid_loader(const GemmArgs& a, char* smem, int lw
             constexpr int Q = 2 * BN;                    // bytes of [S | C] per loader wave: waves 0, 1 -> S, waves 2, 3 -> C
             const long fst = (long)step * a.fold_step_stride;
             const int c0 = (lw & 1) * (Q / 4) + lane * 4;    // tile column of this lane's 16 B
-            const float* src = (lw < 2 ? a.fold_S : a.fold_C) + fst + (ATTN ? mid_attn_col(c0 < BN ? c0 : 0, n0 / BN, a.N / 3) : n0 + c0);
+            const float* src = (lw < 2 ? a.fold_S : a.fold_C) + fst + (ATTN == MID_ATTN_SELF ? mid_attn_col(c0 < BN ? c0 : 0, n0 / BN, a.N / 3) : n0 + c0);
             char* dst = smem + C::RING + (lw < 2 ? MID_S_OFF : MID_C_OFF) + (lw & 1) * Q;
             if (lane * 16 < Q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -501,10 +515,76 @@ __device__ __forceinline__ void mid_epilogue_attn(const GemmArgs& a, f32x4 (&acc
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused cross-attention epilogue
+// q projection + cross-attention in one launch (model/layers.py:183-200 with N = 32 queries, M = 32 condition tokens, head dim 64; the K | V rows
+// of the condition are step-invariant and cached by the caller).  The 64 x 64 tile is q of ONE head for TWO whole samples; the loader waves bring
+// that head's K and V rows of the two samples into LDS ahead of the operand stream (16 KB, swizzled like the operands).  Compute wave w runs
+// sample w >> 1, queries [16 (w & 1), +16): S^T = K Q^T (4 MFMAs), softmax over the 32 keys, O^T = V^T P^T (4 MFMAs) — the math and the operand
+// layouts of mid_epilogue_attn.  q never reaches HBM and the attention launch of every cross-attention block is gone.
+#define MID_XQ_STRIDE 144            /* bytes per staged q row (64 bf16 + pad): conflict-free 16-B fragment reads */
+__device__ __forceinline__ void mid_epilogue_xattn(const GemmArgs& a, f32x4 (&acc)[1][4], int m0, int head, int wn, int lane, char* tq, const char* kv) {
+    const int lrow = lane & 15, lchk = lane >> 4;
+    const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + head * 64 + wn * 16 + lchk * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const f32x4 v = acc[0][mi];
+        const bf16x4 pk = {(bf16_t)(v[0] + b4[0]), (bf16_t)(v[1] + b4[1]), (bf16_t)(v[2] + b4[2]), (bf16_t)(v[3] + b4[3])};
+        *reinterpret_cast<bf16x4*>(tq + (mi * 16 + lrow) * MID_XQ_STRIDE + (wn * 16 + lchk * 4) * 2) = pk;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MID_BARRIER();                                       // the four compute waves (the loader waves have ended): the q tile is complete
+    const int sp = wn >> 1, qh = wn & 1;
+    const char* ks = kv + (sp * 2) * 4096;
+    const char* vs = ks + 4096;
+    const char* qs = tq + (sp * 32 + qh * 16 + lrow) * MID_XQ_STRIDE;
+    f32x4 st[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // lane holds S[key = kt*16 + lchk*4 + r][query = lrow]
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (k2 * 32 + lchk * 8) * 2);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int row = kt * 16 + lrow;
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * 128 + (((k2 * 4 + lchk) ^ ((row >> 1) & 7)) << 4));
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, st[kt], 0, 0, 0);
+        }
+    }
+    const float cs = a.attn_scale_log2e;
+    float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * cs;
+    float p[8], l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[kt * 4 + r] = __builtin_amdgcn_exp2f(st[kt][r] * cs - mc); l += p[kt * 4 + r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float linv = 1.0f / l;
+    // P^T operand: k-slot j of lane group lchk = key (j < 4 ? lchk*4 + j : 16 + lchk*4 + j - 4): the accumulator layout's key order, on both operands
+    const bf16x8 pf = {(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3], (bf16_t)p[4], (bf16_t)p[5], (bf16_t)p[6], (bf16_t)p[7]};
+    bf16_t* ob = a.attn_o + ((((long)(m0 / 32 + sp)) * (a.N / 64) + head) * 32 + qh * 16 + lrow) * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bf16x8 vf;
+        const int c = dt * 2 + (lrow >> 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = (j < 4) ? lchk * 4 + j : 16 + lchk * 4 + (j - 4);
+            vf[j] = *reinterpret_cast<const bf16_t*>(vs + key * 128 + ((c ^ ((key >> 1) & 7)) << 4) + (lrow & 7) * 2);
+        }
+        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // lane holds O[query = lrow][d = dt*16 + lchk*4 + r]
+        const bf16x4 pk = {(bf16_t)(o[0] * linv), (bf16_t)(o[1] * linv), (bf16_t)(o[2] * linv), (bf16_t)(o[3] * linv)};
+        *reinterpret_cast<bf16x4*>(ob + dt * 16 + lchk * 4) = pk;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
-template <int EPI, int BM, int BN, int FOLD = MID_FOLD_NONE, bool ATTN = false>
+template <int EPI, int BM, int BN, int FOLD = MID_FOLD_NONE, int ATTN = MID_ATTN_NONE>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a) {
-    static_assert(!ATTN || (EPI == EPI_BF16 && BM == 128 && BN == 192 && FOLD != MID_FOLD_PRODUCER), "fused attention: the 128 x 192 bf16 form");
+    static_assert(ATTN != MID_ATTN_SELF || (EPI == EPI_BF16 && BM == 128 && BN == 192 && FOLD != MID_FOLD_PRODUCER), "fused self-attention: the 128 x 192 bf16 form");
+    static_assert(ATTN != MID_ATTN_CROSS || (EPI == EPI_BF16 && BM == 64 && BN == 64 && FOLD == MID_FOLD_NONE), "fused cross-attention: the 64 x 64 bf16 form");
     using C = MidCfg<BM, BN>;
     constexpr int NT = C::NT, MT = C::MT;
     extern __shared__ __attribute__((aligned(16))) char smem_mid[];
@@ -553,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     {
         const int prow = wn * 64 + lane;                 // row of the panel this lane touches (BN = 128: waves 0, 1 cover it)
         if (prow < BN) {
-            const char* wl = reinterpret_cast<const char*>(a.W + (long)(ATTN ? mid_attn_col(prow, tile_n, a.N / 3) : n0 + prow) * a.ldw + kbase);
+            const char* wl = reinterpret_cast<const char*>(a.W + (long)(ATTN == MID_ATTN_SELF ? mid_attn_col(prow, tile_n, a.N / 3) : n0 + prow) * a.ldw + kbase);
             char* dst = smem_mid + C::RING + wave * 4096;
             int cnt = 0;
             for (int j = tile_m + (tile_m < 3 ? tiles_m : 0); j < nkt && cnt < 6; j += tiles_m, ++cnt)   // (K-tiles 0-2 are requested at once anyway; 6 x 256 B: the staging area's head)
@@ -726,10 +806,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_mid_kernel(const GemmArgs a)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ATTN) {
+    if constexpr (ATTN == MID_ATTN_SELF) {
         // every compute wave is past its last ring read before the ring becomes the q | k | v tile
         MID_BARRIER();
         mid_epilogue_attn<FOLD>(a, acc, m0, tile_n, wn, lane, smem_mid, smem_mid + C::RING);
+    } else if constexpr (ATTN == MID_ATTN_CROSS) {
+        MID_BARRIER();                                   // (as above: the ring becomes the q tile)
+        mid_epilogue_xattn(a, acc, m0, tile_n, wn, lane, smem_mid, smem_mid + C::LDS);
     } else
         mid_epilogue<EPI, BM, BN, FOLD>(a, acc, m0, n0 + wn * (BN / 4), wn, lane, smem_mid + C::RING + wave * 4096, smem_mid + C::RING, rpre, step);
 #ifdef MID_STAMPS
@@ -865,8 +948,8 @@ bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a_in, hipStream_t stream, 
 template <int FOLD>
 static int mid_qkv_attn_launch(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = MidCfg<128, 192>::LDS;
-    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, true>), lds, "gemm_mid(qkv+attention)");
-    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, true>), dim3((unsigned)((a.M / 128) * (a.N / 192))), dim3(512), lds, stream, a);
+    LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, MID_ATTN_SELF>), lds, "gemm_mid(qkv+attention)");
+    hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI_BF16, 128, 192, FOLD, MID_ATTN_SELF>), dim3((unsigned)((a.M / 128) * (a.N / 192))), dim3(512), lds, stream, a);
     return ldt_check_launch("gemm_bf16_nt_mid(qkv+attention)");
 }
 
@@ -880,5 +963,30 @@ bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a_in, int tokens, int head_dim, b
     GemmArgs a = g;
     a.col_major = 1;
     *status = folded ? mid_qkv_attn_launch<MID_FOLD_CONSUMER>(a, stream) : mid_qkv_attn_launch<MID_FOLD_NONE>(a, stream);
+    return true;
+}
+
+// q projection + cross-attention in one launch (mid_epilogue_xattn): 32-token samples, 32 condition tokens, head dim 64, N = hidden (a multiple
+// of 64), whole 64-row tiles (two samples each), one or two rounds of workgroups.  a->attn_k / attn_v: the cached K | V rows of the condition
+// (row stride attn_ldkv, sample stride attn_kv_batch_stride, elements).  LDT_Q_XATTN=0: off (A/B).
+bool ldt_gemm_mid_q_xattn_try(const GemmArgs* a_in, int tokens, int cond_tokens, int head_dim, hipStream_t stream, int* status) {
+    static const bool on = !(getenv("LDT_Q_XATTN") && atoi(getenv("LDT_Q_XATTN")) == 0);
+    const GemmArgs& g = *a_in;
+    if (!on || !mid_env() || tokens != 32 || cond_tokens != 32 || head_dim != 64 || !g.attn_o || !g.attn_k || !g.attn_v) return false;
+    if (g.N % 64 != 0 || g.M % 64 != 0 || g.K % MID_BK != 0 || g.K / MID_BK < 2) return false;
+    const long wgs = (long)(g.M / 64) * (g.N / 64);
+    if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) return false;
+    if (!ldt_aligned16(g.attn_o) || !ldt_aligned16(g.attn_k) || !ldt_aligned16(g.attn_v) || g.attn_ldkv % 8 != 0 || g.attn_kv_batch_stride % 8 != 0 ||
+        (g.bias && !ldt_aligned16(g.bias)) || g.ldx % 8 != 0 || g.ldw % 8 != 0)
+        return false;
+    GemmArgs a = g;
+    a.col_major = 1;
+    constexpr int lds = MidCfg<64, 64>::LDS + MID_XKV_BYTES;
+    auto launch = [&]() -> int {
+        LDT_ENSURE_LDS((&gemm_bf16_nt_mid_kernel<EPI_BF16, 64, 64, MID_FOLD_NONE, MID_ATTN_CROSS>), lds, "gemm_mid(q+cross-attention)");
+        hipLaunchKernelGGL((gemm_bf16_nt_mid_kernel<EPI_BF16, 64, 64, MID_FOLD_NONE, MID_ATTN_CROSS>), dim3((unsigned)wgs), dim3(512), lds, stream, a);
+        return ldt_check_launch("gemm_bf16_nt_mid(q+cross-attention)");
+    };
+    *status = launch();
     return true;
 }

@@ -32,6 +32,8 @@ struct GemmArgs {
     // ---- QKV projection + self-attention in one launch (gemm_mid.hip, 32-token samples, head dim 64): N = 3 * hidden columns [q | k | v];
     // the kernel writes O[B][H][32][64] (the reference's raw (B,N,C) buffer, model/layers.py:190-197) to attn_o and NOT the q | k | v rows
     bf16_t* attn_o; float attn_scale_log2e;
+    // fused q projection + cross-attention (gemm_mid.hip, ldt_gemm_mid_q_xattn_try): the condition's cached K | V rows (elements)
+    const bf16_t* attn_k; const bf16_t* attn_v; long attn_ldkv; long attn_kv_batch_stride;
 };
 
 struct LnArgs {
@@ -77,7 +79,9 @@ int ldt_gemm_mid_shape(int epi, const GemmArgs* a);                // gemm_mid.h
 int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t stream);
 bool ldt_gemm_mid_lnfold_takes(int epi, int M, int N, int K);       // would the LN-folded form (statistics per 32 columns) of this GEMM be taken?
 bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);
-bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);   // fused QKV + attention (32 tokens, Dh 64); false = not taken   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
+bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);
+bool ldt_gemm_mid_q_xattn_try(const GemmArgs* a, int tokens, int cond_tokens, int head_dim, hipStream_t stream, int* status);   // fused q projection + cross-attention (32 x 32 tokens, Dh 64); false = not taken
+//   // fused QKV + attention (32 tokens, Dh 64); false = not taken   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
 bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // small batch: every GEMM of a Score block folds through the mid-size tile kernel (statistics per 32 columns)
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
