@@ -219,8 +219,8 @@ def roofline_pass(trainer, cfg, B, reps=3):
         xr = 1 if name in ("gemm_o", "gemm_dn") and (M // 256) * (D // 256) <= 256 and M % 256 == 0 else 0
         kname = "gemm_bf16_nt_256f_kernel"               # the 256-tile persistent kernel (full-line operand stream)
         sym = ("%s<%d, %d, %d>" % (kname, epi_id[name], fold_id[name] if folded else 0, xr)) if name in epi_id else \
-            {"attention": "attn_fwd_head_kernel<64>" if 128 < T <= 256 and not os.environ.get("LDT_ATTN_FORCE") else "attn_fwd_kernel<64, false>",
-             "ln_modulate": "ln_mod_vec_kernel<4, false>"}.get(name)
+            {"attention": "attn_fwd_head_kernel<64, %d>" % ((T + 63) // 64) if 128 < T <= 256 and not os.environ.get("LDT_ATTN_FORCE") else "attn_fwd_kernel<64, false>",
+             "ln_modulate": "ln_mod_vec_kernel<4>"}.get(name)
         if sym is None:
             continue
         if name in hbm_bytes:                           # HBM-bound kernels: algorithmic bytes / time against 8 TB/s
