@@ -205,6 +205,10 @@ def roofline_pass(trainer, cfg, B, reps=3):
     fold_id = {"gemm_qkv": 2, "gemm_gelu": 2, "gemm_o": 1, "gemm_dn": 1}
     epi_id = {"gemm_qkv": 1, "gemm_gelu": 2, "gemm_o": 4, "gemm_dn": 4}
     kernels, roofs = {}, {}
+    # QKV projection + self-attention as ONE launch (256-token samples: gemm_qkv_attn256_kernel): no attention launches; the class carries both flops
+    fused_attn = tot_cnt[_lib.PROF_CLASSES.index("attention")] == 0 and tot_cnt[_lib.PROF_CLASSES.index("gemm_qkv")] > 0
+    if fused_attn:
+        flops["gemm_qkv"] += flops["attention"]
     for c, name in enumerate(_lib.PROF_CLASSES):
         if tot_cnt[c] == 0:
             continue
@@ -218,7 +222,8 @@ def roofline_pass(trainer, cfg, B, reps=3):
         # rocprofv3 symbol: <epilogue id, LN folding (1 producer, 2 consumer), residual rows through the operand ring (one tile per workgroup)>
         xr = 1 if name in ("gemm_o", "gemm_dn") and (M // 256) * (D // 256) <= 256 and M % 256 == 0 else 0
         kname = "gemm_bf16_nt_256f_kernel"               # the 256-tile persistent kernel (full-line operand stream)
-        sym = ("%s<%d, %d, %d>" % (kname, epi_id[name], fold_id[name] if folded else 0, xr)) if name in epi_id else \
+        sym = ("gemm_qkv_attn256_kernel<%d>" % (2 if folded else 0)) if (name == "gemm_qkv" and fused_attn) else \
+            ("%s<%d, %d, %d>" % (kname, epi_id[name], fold_id[name] if folded else 0, xr)) if name in epi_id else \
             {"attention": "attn_fwd_head_kernel<64, %d>" % ((T + 63) // 64) if 128 < T <= 256 and not os.environ.get("LDT_ATTN_FORCE") else "attn_fwd_kernel<64, false>",
              "ln_modulate": "ln_mod_vec_kernel<4>"}.get(name)
         if sym is None:
@@ -234,6 +239,8 @@ def roofline_pass(trainer, cfg, B, reps=3):
         r.update(mfma_util=mu, mfma_util_source=mu_src)
         r.update(traffic=tr_, traffic_source=prov, kernel=sym, op=name, avg_launch_ms=k["avg_ms"], ms_per_forward=k["ms_per_forward"],
                  ln_folding=folded)
+        if name == "gemm_qkv" and fused_attn:
+            r["fused"] = "QKV projection + self-attention of the block in one launch: flops_per_launch = projection + attention"
         roofs[name] = r
     dom = max((n for n in roofs if n.startswith("gemm_")), key=lambda n: kernels[n]["ms_per_forward"])
     return roofs[dom], roofs, kernels
@@ -635,7 +642,7 @@ def main():
             roof, roofs, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
             log("roofline pass done: %s" % json.dumps(kernels))
             line["roofline"] = roof
-            line["roofline_attention"] = roofs.get("attention")
+            line["roofline_attention"] = roofs.get("attention") or {"fused_into": "gemm_qkv: %s" % roofs["gemm_qkv"]["kernel"]}
             line["roofline_kernels"] = roofs
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline and cond is None:

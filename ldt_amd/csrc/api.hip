@@ -269,7 +269,16 @@ struct Prof {
     std::vector<int> cls;
     void begin(int c) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev.push_back(a); ev.push_back(b); cls.push_back(c); (void)hipEventRecord(a, s); }
     void end() { (void)hipEventRecord(ev.back(), s); }
+    void cancel() { (void)hipEventDestroy(ev.back()); ev.pop_back(); (void)hipEventDestroy(ev.back()); ev.pop_back(); cls.pop_back(); }   // begin() without a launch
 };
+// a `..._try` launcher (fused QKV + attention forms): timed as class cls_ when it takes the launch
+#define LAUNCH_TRY(cls_, took_, try_expr, st_)      \
+    do {                                            \
+        if (prof) prof->begin(cls_);                \
+        took_ = (try_expr);                         \
+        if (prof) { if (took_) prof->end(); else prof->cancel(); } \
+        if (took_ && (st_) != LDT_OK) return (st_); \
+    } while (0)
 #define LAUNCH(cls_, expr)                \
     do {                                  \
         if (prof) prof->begin(cls_);      \
@@ -309,8 +318,10 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             // 32-token samples: projection + attention in one launch (gemm_mid.hip, mid_epilogue_attn): q | k | v never reach HBM
             gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
             int fst = LDT_OK;
-            if (fold_v1 && ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, true, s, &fst)) { TRY(fst); }
-            else {
+            bool took = false;
+            if (fold_v1) LAUNCH_TRY(LDT_PROF_GEMM_QKV, took, ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, true, s, &fst), fst);
+            else LAUNCH_TRY(LDT_PROF_GEMM_QKV, took, ldt_gemm_qkv_attn256_try(&gq, T, D / p->heads, true, s, &fst), fst);   // 256-token samples: the 256 x 192-tile form of the persistent kernel
+            if (!took) {
             LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_lnfold_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
@@ -326,8 +337,9 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
             gq.attn_k = BF(p->kv_cond[l]); gq.attn_v = BF(p->kv_cond[l]) + D; gq.attn_ldkv = 2L * D; gq.attn_kv_batch_stride = (long)S * 2 * D;
             int fst = LDT_OK;
-            if (ldt_gemm_mid_q_xattn_try(&gq, T, S, D / p->heads, s, &fst)) { TRY(fst); }   // 32 x 32 tokens: projection + attention in one launch
-            else {
+            bool took = false;
+            LAUNCH_TRY(LDT_PROF_GEMM_QKV, took, ldt_gemm_mid_q_xattn_try(&gq, T, S, D / p->heads, s, &fst), fst);   // 32 x 32 tokens: projection + attention in one launch
+            if (!took) {
             LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->kv_cond[l]), 2L * D, (long)S * 2 * D, BF(p->kv_cond[l]) + D, 2L * D,
                         BFM(p->Ob), p->batch, p->heads, T, S, 1.4426950408889634f / sqrtf((float)(D / p->heads))};
@@ -338,8 +350,10 @@ static int score_forward_impl(const ldt_score_plan* p, const float* x, float* ep
             gq.max_wgs = p->gemm_wgs;
             gq.attn_o = BFM(p->Ob); gq.attn_scale_log2e = 1.4426950408889634f / sqrtf((float)(D / p->heads));
             int fst = LDT_OK;
-            if (ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, false, s, &fst)) { TRY(fst); }   // 32-token samples: projection + attention in one launch
-            else {
+            bool took = false;
+            LAUNCH_TRY(LDT_PROF_GEMM_QKV, took, ldt_gemm_mid_qkv_attn_try(&gq, T, D / p->heads, false, s, &fst), fst);   // 32-token samples: projection + attention in one launch
+            if (!took) LAUNCH_TRY(LDT_PROF_GEMM_QKV, took, ldt_gemm_qkv_attn256_try(&gq, T, D / p->heads, false, s, &fst), fst);   // 256-token samples
+            if (!took) {
             LAUNCH(LDT_PROF_GEMM_QKV, ldt_gemm_launch(LDT_EPI_BF16, &gq, s));
             AttnArgs at{BF(p->QKV), 3L * D, (long)T * 3 * D, BF(p->QKV) + D, 3L * D, (long)T * 3 * D, BF(p->QKV) + 2 * D, 3L * D,
                         BFM(p->Ob), p->batch, p->heads, T, T, 1.4426950408889634f / sqrtf((float)(D / p->heads))};

@@ -9,7 +9,7 @@ mkdir -p "$HERE/build"
 pids=()
 for f in "$HERE"/*.hip; do
   o="$HERE/build/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/kernels.h" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/../../include/ldt_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/kernels.h" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/attn_tile.h" -nt "$o" ] || [ "$HERE/../../include/ldt_hip.h" -nt "$o" ]; then
     extra=""
     case "$(basename "$f")" in fps_wave.hip) extra="-fno-slp-vectorize" ;; esac   # (why: the file's header)
     $HIPCC $FLAGS $extra -c "$f" -o "$o" &

@@ -772,6 +772,327 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the (unused) tail requests before exit
 }
 
+// =================================================================================================
+// QKV projection + self-attention in ONE launch at the bench shape (256-token samples, head dim 64): the v3 kernel on 256 x 192 tiles.
+// A tile is [q | k | v] of ONE head for ONE whole sample (rows = the sample's 256 tokens; the tile's W rows / bias / S | C columns are three
+// 64-wide segments, `hidden` apart), so when its main loop ends the workgroup holds everything that (sample, head)'s attention needs:
+//   * the finished projections (bias or LN-folded form applied) go to LDS as bf16 rows in the whole-head attention kernel's layouts —
+//     q into the staging areas (32 KB), k | v into the operand buffer the last K-tile has just left (64 KB); the OTHER buffer keeps
+//     receiving the next tile's first K-tile meanwhile (this form does not pre-request the second one: V3_PREISSUE needs both buffers);
+//   * wave w (8 of them) then runs query rows [32 w, +32) over the four 64-key tiles with attn_tile_joint — the math, operand layouts and
+//     summation order of attn_fwd_head_kernel — and stores O / l through its own (then dead) q rows: attn_o[B][H][256][64].
+// The q | k | v rows never reach HBM (96 MB written + 96 MB read per block at B = 64) and the attention launch of the block is gone.
+// Wave layout in the main loop: grp = wave >> 2 owns rows [128 grp, +128), wn = wave & 3 owns tile columns [48 wn, +48): 12 MFMAs per
+// phase instead of 16, everything else (phases, barriers, counted waits, tile order) is v3's.
+#include "attn_tile.h"
+#define QA_W_ROWS 192
+template <int FOLD>   // FOLD_NONE (block 0: bias) | FOLD_CONSUMER
+__global__ __launch_bounds__(512) void gemm_qkv_attn256_kernel(const GemmArgs a) {
+    static_assert(FOLD == FOLD_NONE || FOLD == FOLD_CONSUMER, "qkv+attention: plain or LN-folded consumer");
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int lrow = lane & 15, lchk = lane >> 4;
+    const int nkt = a.K >> 6;
+    const int hidden = a.N / 3, heads = hidden / 64;
+
+    // ---- this workgroup's tile list (v3's: 8 contiguous chunks, one per XCD label; grouped order inside); tile = (sample, head)
+    const int tiles_n = heads;
+    const int tiles_m = a.M / 256;
+    const int tiles = tiles_m * tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int nx = G < 8 ? G : 8;
+    const int xcd = bid % nx, j = bid / nx;
+    const int wpx = (G - xcd + nx - 1) / nx;
+    const int c_lo = (int)((long)tiles * xcd / nx), c_hi = (int)((long)tiles * (xcd + 1) / nx);
+    const int my_tiles = (c_hi - c_lo - j + wpx - 1) / wpx > 0 ? (c_hi - c_lo - j + wpx - 1) / wpx : 0;
+    if (my_tiles == 0) return;
+    const int gm = a.group_m;
+    auto tile_of = [&](int it, int& m0, int& hd) {
+        const int id = c_lo + j + it * wpx;
+        if (gm <= 1) { m0 = (id / tiles_n) * 256; hd = id % tiles_n; return; }
+        const int per = gm * tiles_n, g = id / per, r = id - g * per;
+        const int rows = min(gm, tiles_m - g * gm);
+        m0 = (g * gm + r % rows) * 256; hd = r / rows;
+    };
+
+    // ---- operand stream: W = 24 pieces per K-tile (3 per wave; piece pj = rows [8 pj, +8) of the tile's 192 = segment pj / 8), X as v3
+    int wvo[3], xavo[2], xbvo[2];
+    int wds[3], xads[2], xbds[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pj = wave * 3 + q;
+        const int r = pj * 8 + (lane >> 3);                              // row of the tile's W image
+        const int gr = (pj >> 3) * hidden + (r & 63);                    // row of W relative to the head's first q row
+        wvo[q] = gr * (int)a.ldw * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        wds[q] = V3_OPER_BYTES + pj * 1024;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pj = wave * 2 + q;
+        const int r0 = pj < 8 ? pj * 8 : 128 + (pj - 8) * 8;
+        const int ra = r0 + (lane >> 3), rb = ra + 64;
+        xavo[q] = ra * (int)a.ldx * 2 + (((lane & 7) ^ ((ra >> 1) & 7)) << 4);
+        xbvo[q] = rb * (int)a.ldx * 2 + (((lane & 7) ^ ((rb >> 1) & 7)) << 4);
+        xads[q] = r0 * 128;
+        xbds[q] = (r0 + 64) * 128;
+    }
+    const char* sxb = nullptr;
+    const char* swb = nullptr;
+    int s_it = 0, s_kt = 0, s_inc = 128;
+    auto seek = [&](int it) {
+        int m0, hd;
+        tile_of(it, m0, hd);
+        sxb = reinterpret_cast<const char*>(a.X + (long)m0 * a.ldx);
+        swb = reinterpret_cast<const char*>(a.W + (long)hd * 64 * a.ldw);
+    };
+    auto advance = [&]() {
+        sxb += s_inc; swb += s_inc;
+        if (++s_kt == nkt) {
+            s_kt = 0;
+            if (++s_it < my_tiles) seek(s_it);
+            else { sxb -= s_inc; swb -= s_inc; s_inc = 0; s_kt = -0x40000000; }   // parked: re-reads the last K-tile, never consumed
+        }
+    };
+    int gk = 0;
+    auto issue_w = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(swb + wvo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + wds[q]), 16, 0, 0);
+    };
+    auto issue_xa = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sxb + xavo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + xads[q]), 16, 0, 0);
+    };
+    auto issue_xb = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sxb + xbvo[q]),
+                                             (__attribute__((address_space(3))) void*)(buf + xbds[q]), 16, 0, 0);
+    };
+    seek(0);
+    const int step = ((FOLD != FOLD_NONE) && a.step_ptr) ? *a.step_ptr : 0;
+    const float* fold_S = (FOLD == FOLD_CONSUMER) ? a.fold_S + (long)step * a.fold_step_stride : nullptr;
+    const float* fold_C = (FOLD == FOLD_CONSUMER) ? a.fold_C + (long)step * a.fold_step_stride : nullptr;
+
+    issue_w(smem2); issue_xa(smem2); issue_xb(smem2); advance();
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // W + first X half landed (this wave's pieces)
+    V2_BARRIER();
+
+    const int sw = (lrow >> 1) & 7;
+    const int xrb = (grp * 128 + lrow) * 128, wrb = V3_OPER_BYTES + (wn * 48 + lrow) * 128;
+    const int xb0 = xrb + ((lchk ^ sw) << 4), xb1 = xrb + (((4 + lchk) ^ sw) << 4);
+    const int wb0 = wrb + ((lchk ^ sw) << 4), wb1 = wrb + (((4 + lchk) ^ sw) << 4);
+    constexpr int EPI_VMEM = 4;                                          // VMEM ops of the epilogue behind the stream's last request: the four O stores
+    bool prev_staged = false;
+    const int r32 = lane & 31, hh = lane >> 5;
+    AttnLaneOffs<64> lo;
+    lo.init(lane);
+
+    for (int it = 0; it < my_tiles; ++it) {
+        int m0, hd;
+        tile_of(it, m0, hd);
+        f32x4 acc[3][8];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (block 0: the bias of this lane's columns, fetched ahead of the main loop so that the epilogue issues no load)
+        f32x4 add4[3];
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            const int c = wn * 48 + ni * 16 + lchk * 4;
+            add4[ni] = (FOLD == FOLD_NONE && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + (c >> 6) * hidden + hd * 64 + (c & 63)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
+
+        enum { KT_PLAIN = 0, KT_FIRST = 1, KT_FOLD_DMA = 4, KT_FOLD_FINAL = 8 };
+        auto ktile = [&](auto flags_c) {
+            constexpr int FL = decltype(flags_c)::value;
+            const char* st = smem2 + (gk & 1) * V3_BUF_BYTES;
+            char* nb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;
+            bf16x8 wf[3], xf[4];
+            // ---------------- p0
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048);
+            issue_w(nb);
+            if (FL & KT_FOLD_DMA) {
+                char* stage_reg = smem2 + V2_RING_BYTES + wave * 4096;
+                if (wave < 2 * a.stats_parts) {
+                    const float* src = a.stats_in + ((long)(wave >> 1) * a.M + m0 + (wave & 1) * 128) * 2 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_STATS_OFF), 16, 0, 0);
+                }
+                if (wave < 6 && lane < 16) {                             // S segments -> waves 0-2's areas, C segments -> waves 3-5's
+                    const int seg = wave < 3 ? wave : wave - 3;
+                    const float* src = (wave < 3 ? fold_S : fold_C) + seg * hidden + hd * 64 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage_reg + V2_SC_OFF), 16, 0, 0);
+                }
+            }
+            if ((FL & KT_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
+            constexpr int P0W = 3;
+            if ((FL & KT_FIRST) && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W + EPI_VMEM) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W) : "memory");
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + (4 + i) * 2048);
+            issue_xa(nb);
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p2
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048);
+            issue_xb(nb); advance();
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            // ---------------- p3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + (4 + i) * 2048);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // W + first X half of the next K-tile
+            V2_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V2_BARRIER();
+            ++gk;
+        };
+#define KTL(f) std::integral_constant<int, (f)>{}
+        if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 4 K-tiles
+            ktile(KTL(KT_FIRST)); ktile(KTL(KT_FOLD_DMA)); ktile(KTL(KT_PLAIN)); ktile(KTL(KT_FOLD_FINAL));
+            for (int kt = 4; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
+        } else {
+            ktile(KTL(KT_FIRST));
+            for (int kt = 1; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
+        }
+#undef KTL
+        if (grp == 0) V2_BARRIER();                                      // un-stagger: both groups run the epilogue together
+        prev_staged = true;
+
+        // ---- epilogue 1: finish the projection; bf16 rows -> q (staging areas) | k | v (the buffer the last K-tile has just left)
+        char* stage_base = smem2 + V2_RING_BYTES;
+        char* kvb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;               // K: [256 keys][128 B] at + 0, V at + 32 KiB (the other buffer holds the next tile's K-tile 0)
+        f32x4 s4[3];
+        float rr[8], nm[8];
+        if (FOLD == FOLD_CONSUMER) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int R = grp * 128 + mi * 16 + lrow;
+                const f32x2 t = *reinterpret_cast<const f32x2*>(stage_base + (R >> 7) * 4096 + V2_STATS_OFF + (R & 127) * 8);
+                rr[mi] = t[0]; nm[mi] = t[1];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+                const int c = wn * 48 + ni * 16 + lchk * 4;
+                s4[ni] = *reinterpret_cast<const f32x4*>(stage_base + (c >> 6) * 4096 + V2_SC_OFF + (c & 63) * 4);
+                add4[ni] = *reinterpret_cast<const f32x4*>(stage_base + (3 + (c >> 6)) * 4096 + V2_SC_OFF + (c & 63) * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V2_BARRIER();                                                // every wave has its statistics / S | C: the staging areas become the q rows
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int R = grp * 128 + mi * 16 + lrow;
+            const int swr = (R >> 1) & 7;
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+                f32x4 v = acc[ni][mi];
+                if (FOLD == FOLD_CONSUMER) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * rr[mi] + (nm[mi] * s4[ni][r] + add4[ni][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += add4[ni][r];
+                }
+                const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                const int c = wn * 48 + ni * 16 + lchk * 4, seg = c >> 6, cc = c & 63;
+                const int sz = seg == 2 ? ((R >> 1) & 1) << 2 : swr;        // V rows: the transposed-read swizzle; q, k rows: the row-read one
+                char* dst = (seg == 0 ? stage_base : kvb + (seg - 1) * 32768) + R * 128 + (((cc >> 3) ^ sz) << 4) + (cc & 7) * 2;
+                *reinterpret_cast<bf16x4*>(dst) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V2_BARRIER();                                                    // the head's q | k | v are complete
+
+        // ---- epilogue 2: wave w = query rows [32 w, +32) over the four key tiles (attn_fwd_head_kernel's loop)
+        {
+            const int q0 = wave * 32;
+            bf16x8 qf[4];
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI)
+                qf[sI] = *reinterpret_cast<const bf16x8*>(stage_base + (q0 + r32) * 128 + (((hh + 2 * sI) ^ ((r32 >> 1) & 7)) << 4));
+            f32x16 oacc[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+            float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t)
+                attn_tile_joint<64>(kvb + t * 8192, kvb + 32768 + t * 8192, qf, oacc, m_run, l_run, t * 64, 256, hh, a.attn_scale_log2e, lo);
+            // O / l through this wave's own q rows (dead: the fragments are in registers), whole rows out
+            char* ost = stage_base + q0 * 128;
+            const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chn = d * 4 + g;
+                    const bf16x4 pk = {(bf16_t)(oacc[d][4 * g + 0] * inv), (bf16_t)(oacc[d][4 * g + 1] * inv),
+                                       (bf16_t)(oacc[d][4 * g + 2] * inv), (bf16_t)(oacc[d][4 * g + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(ost + r32 * 128 + ((chn ^ (r32 & 7)) << 4) + hh * 8) = pk;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bf16_t* ob = a.attn_o + (((long)(m0 >> 8) * heads + hd) * 256 + q0) * 64;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int row = p4 * 8 + (lane >> 3), ch = lane & 7;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(ost + row * 128 + ((ch ^ (row & 7)) << 4));
+                *reinterpret_cast<bf16x8*>(ob + (long)row * 64 + ch * 8) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V2_BARRIER();                                                    // k | v (the next K-tile 1's buffer) and the staging areas are free again
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
 static std::atomic<int> g_group_m{-1};
 extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LDT_OK; }
@@ -819,6 +1140,43 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD>), V2_LDS_BYTES, "gemm256f");
     hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
     return ldt_check_launch("gemm_bf16_nt_256f");
+}
+
+static int gemm_variant_env();
+// QKV projection + self-attention in one launch at 256 tokens (gemm_qkv_attn256_kernel): head dim 64, N = 3 * hidden (hidden % 64 == 0),
+// whole samples (M % 256 == 0), enough (sample, head) tiles to fill 5/8 of the workgroups the launch may use.  `folded`: a = the LN-folded
+// consumer's arguments (statistics per 256 columns).  -> true when this kernel took the launch.  LDT_QKV_ATTN256=0: off (A/B).
+bool ldt_gemm_qkv_attn256_try(const GemmArgs* a_in, int tokens, int head_dim, bool folded, hipStream_t stream, int* status) {
+    static const bool on = !(getenv("LDT_QKV_ATTN256") && atoi(getenv("LDT_QKV_ATTN256")) == 0);
+    const GemmArgs& g = *a_in;
+    if (!on || gemm_variant_env() != 0 || tokens != 256 || head_dim != 64 || !g.attn_o) return false;
+    if (g.N % 192 != 0 || (g.N / 3) % 64 != 0 || g.M % 256 != 0 || g.K % 64 != 0 || g.K < (folded ? 256 : 128)) return false;
+    if (folded && (g.stats_parts <= 0 || g.stats_parts > 4 || g.stats_parts * 256 != g.K || !g.stats_in || !g.fold_S || !g.fold_C ||
+                   !ldt_aligned16(g.stats_in) || !ldt_aligned16(g.fold_S) || !ldt_aligned16(g.fold_C) || g.fold_step_stride % 4 != 0))
+        return false;
+    if (!ldt_aligned16(g.X) || !ldt_aligned16(g.W) || !ldt_aligned16(g.attn_o) || (g.bias && !ldt_aligned16(g.bias)) || g.ldx % 8 != 0 || g.ldw % 8 != 0 ||
+        g.ldx < g.K || g.ldw < g.K)
+        return false;
+    const int tm = g.M / 256, tn = (g.N / 3) / 64;
+    const long tiles = (long)tm * tn;
+    const int lim = (g.max_wgs > 0 && g.max_wgs < LDT_NUM_CUS) ? g.max_wgs : LDT_NUM_CUS;
+    if (tiles * 8 < (long)lim * 5) return false;
+    GemmArgs a = g;
+    static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;
+    a.group_m = gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
+    const int grid = tiles < lim ? (int)tiles : lim;
+    auto launch = [&]() -> int {
+        if (folded) {
+            LDT_ENSURE_LDS((&gemm_qkv_attn256_kernel<FOLD_CONSUMER>), V2_LDS_BYTES, "gemm_qkv_attn256");
+            hipLaunchKernelGGL((gemm_qkv_attn256_kernel<FOLD_CONSUMER>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, a);
+        } else {
+            LDT_ENSURE_LDS((&gemm_qkv_attn256_kernel<FOLD_NONE>), V2_LDS_BYTES, "gemm_qkv_attn256");
+            hipLaunchKernelGGL((gemm_qkv_attn256_kernel<FOLD_NONE>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, a);
+        }
+        return ldt_check_launch("gemm_qkv_attn256");
+    };
+    *status = launch();
+    return true;
 }
 
 // LN-folding launches.  Large batches: the 256-tile kernel (statistics per 256 columns).  Small batches — all four GEMMs of a Score block

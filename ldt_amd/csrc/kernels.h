@@ -80,6 +80,7 @@ int ldt_gemm_mid_launch(int epi, int shape, const GemmArgs* a, hipStream_t strea
 bool ldt_gemm_mid_lnfold_takes(int epi, int M, int N, int K);       // would the LN-folded form (statistics per 32 columns) of this GEMM be taken?
 bool ldt_gemm_mid_lnfold_try(int epi, const GemmArgs* a, hipStream_t stream, int* status);
 bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);
+bool ldt_gemm_qkv_attn256_try(const GemmArgs* a, int tokens, int head_dim, bool folded, hipStream_t stream, int* status);   // gemm_bf16.hip: fused QKV + self-attention at 256 tokens, Dh 64; false = not taken
 bool ldt_gemm_mid_q_xattn_try(const GemmArgs* a, int tokens, int cond_tokens, int head_dim, hipStream_t stream, int* status);   // fused q projection + cross-attention (32 x 32 tokens, Dh 64); false = not taken
 //   // fused QKV + attention (32 tokens, Dh 64); false = not taken   // LN-folded producer / consumer (statistics per 32 columns); false = not taken
 bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // small batch: every GEMM of a Score block folds through the mid-size tile kernel (statistics per 32 columns)

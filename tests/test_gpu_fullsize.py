@@ -207,6 +207,61 @@ def test_fullsize_vipc_conditioned_vs_oracle(full):
     assert e_fwd < 1e-4 and max(curve) < 1e-4 and e_fin < 1e-4, (e_fwd, curve, e_fin)
 
 
+def test_fused_qkv_attention_256_matches_two_kernel_path(tmp_path):
+    """QKV projection + self-attention in one launch at the bench shape (csrc/gemm_bf16.hip, gemm_qkv_attn256_kernel: 256 x 192 tiles = one
+    head of one 256-token sample, the whole-head attention loop as the epilogue) against the QKV GEMM + attention kernel pair it replaces
+    (LDT_QKV_ATTN256=0): the same seeded forwards at the production width (hidden 1024, 16 heads; 4 blocks) in two child processes —
+    B = 64 with batch-shared modulation (blocks >= 1 LN-folded consumer form, block 0 the plain form with bias) and with per-sample times
+    (every block the plain form behind the LayerNorm kernel), B = 16 (256 tiles = one per workgroup) — three forwards each (run-to-run
+    differences would betray a race in the q | k | v hand-over or a mis-counted wait).  Same operand rounding (q, k, v to bf16) and the same
+    attention loop (attn_tile_joint) on both sides: <= 1e-6 relative MSE (identical up to where the two GEMM kernels order their sums)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    child = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import ldt_amd
+cfg = ldt_amd.airplane_config(latent_tokens=256, sample_N=10, **{"score.num_blocks": 4})
+torch.manual_seed(3)
+comp = ldt_amd.Compressor(cfg.compressor); comp.init()
+score = ldt_amd.Trainer(cfg, ldt_amd.Score(cfg.score), comp, "cuda:0").model
+outs = {}
+for B in (64, 16):
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 256, cfg.score.z_dim, generator=g).cuda(); t = (torch.rand(B, generator=g) * 0.98 + 0.01).cuda()
+    for name, fn in (("shared", lambda: score.forward_shared_t(x, 0.37)), ("per_sample", lambda: score(x, t))):
+        ref = None
+        for rep in range(3):
+            o = fn().float().cpu()
+            assert bool(torch.isfinite(o).all())
+            if ref is not None: assert torch.equal(ref, o), "run-to-run difference"
+            ref = o
+        outs["%%s_%%d" %% (name, B)] = ref
+    # which path ran: the fused kernel never writes the q | k | v rows of the workspace
+    ws = score._workspace(B, 256)
+    ws["QKV"].fill_(7.0)
+    score.forward_shared_t(x, 0.37)
+    torch.cuda.synchronize()
+    outs["qkv_untouched_%%d" %% B] = torch.tensor(float(bool((ws["QKV"] == 7.0).all())))
+torch.save(outs, sys.argv[1])
+''' % ROOT
+    res = {}
+    for flag in ("1", "0"):
+        out = tmp_path / ("qa%s.pt" % flag)
+        r = subprocess.run([sys.executable, "-c", child, str(out)], env=dict(os.environ, LDT_QKV_ATTN256=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = torch.load(out)
+    for k in sorted(res["1"]):
+        if k.startswith("qkv_untouched"):
+            assert float(res["1"][k]) == 1.0 and float(res["0"][k]) == 0.0, (k, res["1"][k], res["0"][k])   # the switch did select the two paths
+            continue
+        e = rel_mse(res["1"][k], res["0"][k])
+        print("fused QKV + attention (256 tokens) vs two kernels, %s: rel. MSE %.2e" % (k, e))
+        assert e < 1e-6, (k, e)
+
+
 def test_fused_cross_attention_matches_two_kernel_path(tmp_path):
     """q projection + cross-attention in one launch (csrc/gemm_mid.hip, mid_epilogue_xattn: 32 queries x 32 condition tokens, head dim 64,
     64 x 64 tiles) against the q GEMM + attention kernel pair it replaces (LDT_Q_XATTN=0), same seeded conditional forward at the production
