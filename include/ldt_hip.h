@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 18
+#define LDT_ABI_VERSION 19
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -170,6 +170,12 @@ int ldt_vpsde_score(const float* params, const float* t, float beta0, float beta
 int ldt_sde_score(const float* params, const float* t, int32_t kind, float c0, float c1, float c2, float* out, int32_t B,
                   int64_t per_sample, void* stream);
 int ldt_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* ldt_block_activation: x = act(x) in place on bf16 rows [M][C] (row stride ld, elements) — the block activation of the reference's
+ *   no-condition ResidualBlock branches (`decoder_act`: model/layers.py:224-226, `self.act` from tools/utils.py:104-124), applied to the
+ *   LayerNorm output that fc_q / the MLP read.  rrelu in its eval-mode form. */
+enum ldt_block_act { LDT_BACT_NONE = 0, LDT_BACT_GELU = 1, LDT_BACT_SILU = 2, LDT_BACT_RELU = 3, LDT_BACT_LEAKY_001 = 4, LDT_BACT_LEAKY_02 = 5,
+                     LDT_BACT_RRELU_EVAL = 6, LDT_BACT_HARDSWISH = 7, LDT_BACT_SELU = 8 };
+int ldt_block_activation(uint16_t* x, int64_t ld, int64_t M, int32_t C, int32_t kind, void* stream);
 int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
 
 /* LN-folding monitor: *out = max over the M rows of mean^2 / variance, from the row statistics stats[parts][M][2] a

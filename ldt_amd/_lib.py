@@ -8,11 +8,18 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = range(4)
+# enum ldt_block_act: tools/utils.py:104-124 get_activation (unknown names fall to ReLU there; rrelu in eval mode)
+BLOCK_ACTS = {"gelu": 1, "silu": 2, "swish": 2, "relu": 3, "leakyrelu": 4, "leakyrelu0.2": 5, "rrelu": 6, "hardswish": 7, "selu": 8}
+
+
+def block_act_id(name):
+    """None -> 0 (Identity); a name -> its enum ldt_block_act value (anything unknown is ReLU, as upstream)."""
+    return 0 if name is None else BLOCK_ACTS.get(str(name).lower(), 3)
 PROF_CLASSES = ("other", "gemm_io", "ln_modulate", "gemm_qkv", "attention", "gemm_o", "gemm_gelu", "gemm_dn")
 
 _vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
@@ -65,6 +72,7 @@ SIGNATURES = {
     "ldt_vpsde_score": [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
     "ldt_sde_score": [_vp, _vp, _i32, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
     "ldt_add_f32": [_vp, _vp, _vp, _i64, _vp],
+    "ldt_block_activation": [_vp, _i64, _i64, _i32, _i32, _vp],
     "ldt_widen_bf16": [_vp, _vp, _i64, _vp],
     "ldt_fold_mean_ratio": [_vp, _i32, _i64, _i32, _vp, _vp],
     "ldt_fps": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],

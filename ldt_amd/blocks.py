@@ -11,7 +11,7 @@ Head merge (quirk Q1): the attention kernel writes [B][H][N][Dh]; that buffer *i
 import torch
 
 from . import ops
-from ._lib import ACT_SILU, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32
+from ._lib import ACT_SILU, EPI_BF16, EPI_GELU_BF16, EPI_RESID_F32, block_act_id
 from .layers import conv_w
 
 
@@ -39,6 +39,7 @@ def pack_block(blk):
         "wdn": _bf(conv_w(blk.mlp.out)), "bdn": blk.mlp.out.bias.detach().float().contiguous(),
         "n1": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm1.affine),
         "n2": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm2.affine),
+        "act": block_act_id(getattr(blk, "act", None)),             # activation behind the norms of the no-condition branch (0 = Identity)
     }
     if C == Co and C in (64, 128) and blk.dim_kv == C:              # fc_q | fc_kv as one operand for the fused LN + linear kernel
         P["wqkv"] = torch.cat([P["wq"], P["wkv"]], 0).contiguous()
@@ -81,7 +82,10 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
     else:
         g1 = g2 = None
         s2 = 0
-    fused_in = FUSED_ATTN and C in (64, 128) and P["wq"].shape[1] == C and Co % 64 == 0 and x.stride(0) % 4 == 0
+    # no-condition branch with a block activation (layers.py:224-226, `decoder_act`): act(norm1(x)) feeds fc_q (and fc_kv in self-attention),
+    # act(norm2(x)) the MLP — the LayerNorm kernels + one element-wise pass + the GEMMs (the fused LN kernels have no activation slot)
+    act = P.get("act", 0) if c is None else 0
+    fused_in = FUSED_ATTN and C in (64, 128) and P["wq"].shape[1] == C and Co % 64 == 0 and x.stride(0) % 4 == 0 and not act
     if fused_in:
         # LN1 (+ modulate | affine) + fc_q [+ fc_kv on the same normalised input] in ONE kernel (csrc/fused_mlp.hip):
         # the normalised activations are never written
@@ -101,6 +105,8 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
             h = ops.layernorm_modulate(x, **ln_kw)
         else:
             h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
+            if act:
+                ops.block_activation_(h, act)
         q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
         if y_bf16 is None and kv_pre is None:
             y_bf16, Nk = h, Nq
@@ -117,7 +123,7 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
         a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)     # [B,H,Nq,Dh] == (B*Nq, Co) raw view
         ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
                       gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=rps)
-    if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0:
+    if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0 and not act:
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
         nxt = None
         if next_P is not None and FUSED_ATTN and next_P["C"] == next_P["Co"] == Co and tuple(next_P["wq"].shape) == (Co, Co) \
@@ -136,6 +142,8 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
         h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
     else:
         h2 = ops.layernorm_modulate(x, w=P["n2"][0], b=P["n2"][1])
+        if act:
+            ops.block_activation_(h2, act)
     u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
     ops.gemm_bf16(u, P["wdn"], P["bdn"], EPI_RESID_F32, out=x, resid=x, gate=g2,
                   gate_sample_stride=s2 if g2 is not None else 0, rows_per_sample=rps)

@@ -203,8 +203,11 @@ class Compressor(nn.Module):
         self.norm_input = cfg.norm_input
         self.pre_group = cfg.pre_group
         self.class_condition = cfg.class_condition
-        if not cfg.ActNorm or cfg.decoder_act is not None or not cfg.AdaLN:
-            raise NotImplementedError("Compressor option outside the built configurations (ActNorm off / decoder_act / AdaLN off)")
+        # (cfg.AdaLN is stored and never read upstream — Network.py:133; the Encoder blocks are built with their default AdaLN=True, :148-150 —
+        #  so it is accepted and ignored here too; `decoder_act` = the activation behind the norms of the decoder blocks' no-condition branch,
+        #  layers.py:224-226; `ActNorm: ~` drops the conv_in ActNorm, Network.py:121-123,200-201)
+        self.decoder_act = cfg.decoder_act
+        self.AdaLN = cfg.AdaLN
         # dropout (Network.py:115-116, 148-152) is the identity under eval(), the only mode the encode / decode paths run in
         # (trainer/Latent_SDE_Trainer.py:144-145): accepted, and checked against self.training at call time
         self.encoder_dropout_p = float(cfg.encoder_dropout_p or 0.)
@@ -214,7 +217,8 @@ class Compressor(nn.Module):
                                       "(B, p_dim, tokens) position condition (Network.py:197-198), which does not broadcast")
         self.input = nn.Conv1d(self.input_dim, self.hidden_dim, 1)
         self.ActNorm = cfg.ActNorm
-        self.conv_in = ActNorm(self.hidden_dim, self.z_scales, feature_type=cfg.ActNorm)
+        if self.ActNorm is not None:
+            self.conv_in = ActNorm(self.hidden_dim, self.z_scales, feature_type=cfg.ActNorm)
         self.encoder = nn.ModuleList()
         self.decoder = nn.ModuleList()
         self.upsample = nn.ModuleList()
@@ -266,7 +270,8 @@ class Compressor(nn.Module):
 
     def init(self):
         """Network.py:163-165 — marks ActNorm initialised (call after loading a checkpoint)."""
-        self.conv_in.init()
+        if self.ActNorm is not None:
+            self.conv_in.init()
 
     # ------------------------------------------------------------------ packing
     def _device(self):
@@ -315,7 +320,8 @@ class Compressor(nn.Module):
                 le = self.LabelEmbedding
                 P["label"] = {"emb": f32(le.label_emb.weight), "w1": f32(le.mlp[0].weight), "b1": f32(le.mlp[0].bias),
                               "w2": f32(le.mlp[2].weight), "b2": f32(le.mlp[2].bias)}
-            P["an_shift"], P["an_logs"] = f32(self.conv_in.shift.reshape(-1)), f32(self.conv_in.log_scale.reshape(-1))
+            if self.ActNorm is not None:
+                P["an_shift"], P["an_logs"] = f32(self.conv_in.shift.reshape(-1)), f32(self.conv_in.log_scale.reshape(-1))
         self._pack, self._pack_key = P, key
         return P
 
@@ -450,7 +456,8 @@ class Compressor(nn.Module):
             e = PL["emb"][label.to(dev).long()].contiguous()
             l_emb = ops.sgemm(ops.sgemm(e, PL["w1"], PL["b1"], act_out=ACT_SILU), PL["w2"], PL["b2"])
             pos = pos + l_emb
-        ops.actnorm_(tok, P["an_shift"], P["an_logs"], B)
+        if self.ActNorm is not None:
+            ops.actnorm_(tok, P["an_shift"], P["an_logs"], B)
         enc_out = []
         for Pe in P["enc"]:                                                         # Network.py:203-205, 41-45
             for Pa in Pe["atts"]:

@@ -211,6 +211,39 @@ extern "C" int ldt_sde_score(const float* params, const float* t, int32_t kind, 
     return ldt_check_launch("sde_score");
 }
 
+// x = act(x) in place on bf16 rows [M][C] (row stride ld): the block activation of the reference's no-condition ResidualBlock branches
+// (`decoder_act`, model/layers.py:224-226 via tools/utils.py:104-124), applied to the LayerNorm output the projections read.  kind = enum
+// ldt_block_act; the arithmetic runs in fp32.  rrelu is its eval-mode form (slope (1/8 + 1/3) / 2).
+__device__ __forceinline__ float block_act(float v, int kind) {
+    switch (kind) {
+        case LDT_BACT_GELU: return gelu_erf(v);
+        case LDT_BACT_SILU: return silu(v);
+        case LDT_BACT_RELU: return fmaxf(v, 0.f);
+        case LDT_BACT_LEAKY_001: return v > 0.f ? v : 0.01f * v;
+        case LDT_BACT_LEAKY_02: return v > 0.f ? v : 0.2f * v;
+        case LDT_BACT_RRELU_EVAL: return v > 0.f ? v : v * ((1.0f / 8.0f + 1.0f / 3.0f) * 0.5f);
+        case LDT_BACT_HARDSWISH: return v * fminf(fmaxf(v + 3.0f, 0.f), 6.0f) * (1.0f / 6.0f);
+        case LDT_BACT_SELU: return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * (expf(v) - 1.0f));
+        default: return v;
+    }
+}
+__global__ __launch_bounds__(256) void block_act_kernel(bf16_t* __restrict__ x, long ld, long M, int C, int kind) {
+    const long n = M * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        bf16_t* p = x + (i / C) * ld + (i % C);
+        *p = (bf16_t)block_act((float)*p, kind);
+    }
+}
+extern "C" int ldt_block_activation(uint16_t* x, int64_t ld, int64_t M, int32_t C, int32_t kind, void* stream) {
+    LDT_REQUIRE(x && M > 0 && C > 0 && ld >= C, LDT_EARG, "block_activation: bad argument");
+    LDT_REQUIRE(kind > LDT_BACT_NONE && kind <= LDT_BACT_SELU, LDT_EARG, "block_activation: unknown activation %d", kind);
+    long blocks = (M * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(block_act_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<bf16_t*>(x), (long)ld, (long)M, (int)C, (int)kind);
+    return ldt_check_launch("block_activation");
+}
+
 // out = a + b (fp32; c = t_emb + label / image-condition embedding, model/scorenet/score.py:135).  out may alias a or b.
 __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];

@@ -87,8 +87,9 @@ class ResidualBlock(_Holder):
         super().__init__()
         if rescale or dropout_att or dropout_mlp or (dim_c is not None and not AdaLN):
             raise NotImplementedError("ResidualBlock variant not on the shipped path")
-        if act is not None and dim_c is None:
-            raise NotImplementedError("no-condition block with an activation (decoder_act) is not built")
+        # act: the activation behind norm1 / norm2 in the branches WITHOUT AdaLN modulation (layers.py:224-226: a block called without a
+        # condition — the decoder blocks, `decoder_act`); the AdaLN branch (:212-219) never applies it
+        self.act = act
         if dim_out is not None and dim_out != dim_in:
             if dim_c is None:
                 raise NotImplementedError("dim_in != dim_out without a condition is not used by the reference")

@@ -226,6 +226,14 @@ def add_f32(a, b, out=None):
     return out
 
 
+def block_activation_(x, kind):
+    """x (bf16 [M, C], row-major view) = act(x) in place; kind = _lib.block_act_id(name) (> 0)."""
+    _need(x, torch.bfloat16, "x")
+    _rowmajor(x, "x")
+    check(lib().ldt_block_activation(_p(x), x.stride(0), x.shape[0], x.shape[1], int(kind), stream_ptr()), "ldt_block_activation")
+    return x
+
+
 def widen_bf16(w):
     """bf16 -> fp32 copy (exact)."""
     _need(w, torch.bfloat16, "w")

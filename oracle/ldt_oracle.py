@@ -99,7 +99,18 @@ def mlp(sd, prefix, x):
     return linear(sd, prefix + ".out", F.gelu(linear(sd, prefix + ".fc.0.0", x)))
 
 
-def residual_block(sd, prefix, x, y, c, num_heads):
+def block_act(name):
+    """tools/utils.py:104-124 get_activation as a function (eval mode: rrelu = its mean slope; unknown names are ReLU there)."""
+    if name is None:
+        return lambda v: v
+    n = str(name).lower()
+    table = {"gelu": F.gelu, "silu": F.silu, "swish": F.silu, "selu": F.selu, "hardswish": F.hardswish,
+             "leakyrelu": lambda v: F.leaky_relu(v, 0.01), "leakyrelu0.2": lambda v: F.leaky_relu(v, 0.2),
+             "rrelu": lambda v: F.rrelu(v, training=False)}
+    return table.get(n, F.relu)
+
+
+def residual_block(sd, prefix, x, y, c, num_heads, act=None):
     """model/layers.py:202-229.
 
     c is not None  -> AdaLN branch (:212-219), LayerNorm without affine.
@@ -123,9 +134,10 @@ def residual_block(sd, prefix, x, y, c, num_heads):
         x = x + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
         x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
     else:                                # (a block BUILT with a condition but called without one has no affine: :172-173)
-        h = layer_norm(x, sd.get(prefix + ".norm1.norm.weight"), sd.get(prefix + ".norm1.norm.bias"))
+        fa = block_act(act)              # :224-226: self.act behind both norms (`decoder_act`; Identity in the shipped configs)
+        h = fa(layer_norm(x, sd.get(prefix + ".norm1.norm.weight"), sd.get(prefix + ".norm1.norm.bias")))
         x = x + attention(sd, prefix, h, h if y is None else y, num_heads)
-        h = layer_norm(x, sd.get(prefix + ".norm2.norm.weight"), sd.get(prefix + ".norm2.norm.bias"))
+        h = fa(layer_norm(x, sd.get(prefix + ".norm2.norm.weight"), sd.get(prefix + ".norm2.norm.bias")))
         x = x + mlp(sd, prefix + ".mlp", h)
     return x
 
@@ -455,10 +467,10 @@ def initial_set(sd, B, num_points=None, keep_mask=None, seed_eps=None):
     return torch.stack([prior[keep_mask[b]] for b in range(B)], 0)
 
 
-def decoder_block(sd, prefix, o, eps_j, num_heads, c=None):
+def decoder_block(sd, prefix, o, eps_j, num_heads, c=None, act=None):
     """model/Compressor/Network.py:80-83: o <- att1(o, ln(eps_j), c) (K/V raw; c: label embedding under class_condition)."""
     z = linear(sd, prefix + ".ln", eps_j)
-    return residual_block(sd, prefix + ".att1", o, z, c, num_heads)
+    return residual_block(sd, prefix + ".att1", o, z, c, num_heads, act=act)
 
 
 def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
@@ -468,7 +480,7 @@ def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
     for j in range(cfg.n_layers):
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)                 # reversed(self.decoder), :263
         e_j = given_eps[:, :, cfg.z_dim * j: cfg.z_dim * (j + 1)]  # split along channels, :261-262
-        o = decoder_block(sd, blk, o, e_j, cfg.num_heads)
+        o = decoder_block(sd, blk, o, e_j, cfg.num_heads, act=getattr(cfg, "decoder_act", None))
     return linear(sd, "output", o)                                  # postprocess = identity for xyz, :271-275
 
 
@@ -657,7 +669,8 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
         e = sd["LabelEmbedding.label_emb.weight"][label]
         l_emb = linear(sd, "LabelEmbedding.mlp.2", F.silu(linear(sd, "LabelEmbedding.mlp.0", e)))
         pos = pos + l_emb                                                       # :197-198
-    x = act_norm(sd, "conv_in", x)                                              # :200-201
+    if getattr(cfg, "ActNorm", True) is not None:
+        x = act_norm(sd, "conv_in", x)                                          # :200-201
     enc_out = []
     for i in range(cfg.n_layers):                                               # :203-205
         for j in range(cfg.encoder_layers):
@@ -668,12 +681,12 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
     for j in range(cfg.n_layers):                                               # :217-225
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)
         xj = enc_out[-j - 1]
-        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, l_emb, cfg.num_heads)   # :61-74
+        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, l_emb, cfg.num_heads, act=getattr(cfg, "decoder_act", None))   # :61-74
         post = linear(sd, blk + ".prior.1", F.silu(p))                          # :56,:72
         mu = post[..., :cfg.z_dim]
         logvar = post[..., cfg.z_dim:].clamp(cfg.min_sigma, 10.)                # :76
         eps = mu + torch.exp(logvar / 2.) * post_noise[j]                       # :26-29
-        o = decoder_block(sd, blk, o, eps, cfg.num_heads, l_emb)                # :225
+        o = decoder_block(sd, blk, o, eps, cfg.num_heads, l_emb, act=getattr(cfg, "decoder_act", None))   # :225
         all_eps.append(eps); mus.append(mu); logvars.append(logvar)
     out = linear(sd, "output", o)                                               # :231
     return {"set": out, "all_eps": torch.cat(all_eps, dim=-1), "mu": mus, "logvar": logvars,

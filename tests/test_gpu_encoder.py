@@ -230,6 +230,32 @@ def test_compressor_rng_modes(tiny_cfg):
     assert torch.equal(torch.get_rng_state(), s0)
 
 
+def test_compressor_variants_golden(tiny_cfg):
+    """`decoder_act` (the decoder blocks' LayerNorm -> activation -> projection path: ldt_block_activation), `ActNorm: ~` and the dead
+    `AdaLN: False` flag vs outputs captured from the reference (tests/golden/compressor_variants.npz)."""
+    import copy
+    import ldt_amd
+    from conftest import load_golden, rel_mse
+    a, sds = load_golden("compressor_variants")
+    cc = copy.deepcopy(tiny_cfg.compressor)
+    cc.n_layers, cc.encoder_layers = 2, 1
+    for tag, act in (("g", "gelu"), ("l", "leakyrelu0.2"), ("h", "hardswish"), ("r", "anything-else-is-relu")):
+        ca = copy.deepcopy(cc); ca.decoder_act = act
+        comp = ldt_amd.Compressor(ca)
+        comp.load_state_dict(sds["w"], strict=True)
+        comp = comp.cuda(); comp.init()
+        dec = comp.sample((2, 64), given_eps=a["given_eps"].cuda())
+        assert dec.shape == a[tag + "_points"].shape and rel_mse(dec.cpu(), a[tag + "_points"]) < 1e-4, tag
+        r = comp(a["pts"].cuda(), post_noise=list(a[tag + "_post_noise"]))
+        assert rel_mse(r["all_eps"].cpu(), a[tag + "_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a[tag + "_set"]) < 1e-3, tag
+    cn = copy.deepcopy(cc); cn.ActNorm, cn.AdaLN = None, False
+    comp = ldt_amd.Compressor(cn)
+    comp.load_state_dict({k: v for k, v in sds["w"].items() if not k.startswith("conv_in.")}, strict=True)
+    comp = comp.cuda(); comp.init()
+    r = comp(a["pts"].cuda(), post_noise=list(a["n_post_noise"]))
+    assert rel_mse(r["all_eps"].cpu(), a["n_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["n_set"]) < 1e-3
+
+
 def test_compressor_options_golden(tiny_cfg):
     """norm_input + pre_group and the mixture InitialSet (max_outputs None) vs outputs captured from the reference."""
     import copy

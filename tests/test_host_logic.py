@@ -53,7 +53,7 @@ def test_vpsde_tables_and_step_table(tiny_cfg):
 
 def test_score_block_variant_guards(tiny_cfg):
     """dropout > 0 is accepted (identity under eval(), the sampling mode) and refused in training mode at forward time;
-    AdaLN: False — set by no shipped YAML — is refused at construction with a message naming it."""
+    the Score's AdaLN: False blocks — set by no shipped YAML — are refused at construction with a message naming them."""
     import copy
     import ldt_amd
     c = copy.deepcopy(tiny_cfg.score)
@@ -70,9 +70,14 @@ def test_score_block_variant_guards(tiny_cfg):
     comp.train()
     with pytest.raises(RuntimeError, match="call eval"):
         comp.sample((1, 64), given_eps=torch.zeros(1, cc.z_scales, cc.n_layers * cc.z_dim))
-    cc.decoder_act = "relu"
-    with pytest.raises(NotImplementedError):
-        ldt_amd.Compressor(cc)
+    # the Compressor's own variants are built since round 4 (decoder_act, ActNorm: ~, the dead AdaLN flag): construction succeeds, the
+    # decoder blocks carry the activation, an ActNorm-free model has no conv_in.* parameters (tests/test_gpu_encoder.py runs them vs the reference)
+    from ldt_amd._lib import block_act_id
+    cc.decoder_act, cc.AdaLN = "relu", False
+    comp = ldt_amd.Compressor(cc)
+    assert comp.decoder[0].att1.act == "relu" and block_act_id("relu") == 3 and block_act_id("no-such-name") == 3 and block_act_id(None) == 0
+    cc.ActNorm = None
+    assert not any(k.startswith("conv_in.") for k in ldt_amd.Compressor(cc).state_dict())
 
 
 def _sde_cfg(tiny_cfg, name, a):
@@ -219,10 +224,9 @@ def test_unsupported_options_raise(tiny_cfg):
     c.compressor.class_condition, c.compressor.num_categorys = True, 5
     with pytest.raises(NotImplementedError):       # (B, p) label + (B, p, tokens) position condition: does not broadcast upstream either
         ldt_amd.Compressor(c.compressor)
-    c = copy.deepcopy(tiny_cfg)
+    c = copy.deepcopy(tiny_cfg)                    # built since round 4: the decoder blocks' activation (same parameter tree)
     c.compressor.decoder_act = "swish"
-    with pytest.raises(NotImplementedError):
-        ldt_amd.Compressor(c.compressor)
+    assert sorted(ldt_amd.Compressor(c.compressor).state_dict()) == sorted(ldt_amd.Compressor(tiny_cfg.compressor).state_dict())
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="reference tree not present")

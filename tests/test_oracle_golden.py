@@ -255,6 +255,26 @@ def test_compressor_options(tiny_cfg):
     assert rel_mse(O.compressor_decode(sds["d"], cl, a["b_given_eps"]), a["d_points"]) < TOL    # decode never sees a label
 
 
+def test_compressor_variants(tiny_cfg):
+    """`decoder_act` (four activations, incl. an unknown name = ReLU as upstream), `ActNorm: ~` and the dead `AdaLN: False` flag vs outputs
+    captured from the reference (oracle/gen_compressor_variants_golden.py; one shared weight set)."""
+    import copy
+    a, sds = load_golden("compressor_variants")
+    sd = sds["w"]
+    cc = copy.deepcopy(tiny_cfg.compressor)
+    cc.n_layers, cc.encoder_layers = 2, 1
+    for tag, act in (("g", "gelu"), ("l", "leakyrelu0.2"), ("h", "hardswish"), ("r", "anything-else-is-relu")):
+        ca = copy.deepcopy(cc); ca.decoder_act = act
+        dec = O.compressor_decode(sd, ca, a["given_eps"])
+        assert rel_mse(dec, a[tag + "_points"]) < TOL, tag
+        r = O.compressor_encode(sd, ca, a["pts"], list(a[tag + "_post_noise"]))
+        assert rel_mse(r["all_eps"], a[tag + "_all_eps"]) < 1e-9 and rel_mse(r["set"], a[tag + "_set"]) < 1e-9, tag
+    assert rel_mse(a["g_points"], a["l_points"]) > 1e-3                      # the activation matters
+    cn = copy.deepcopy(cc); cn.ActNorm, cn.AdaLN = None, False
+    r = O.compressor_encode({k: v for k, v in sd.items() if not k.startswith("conv_in.")}, cn, a["pts"], list(a["n_post_noise"]))
+    assert rel_mse(r["all_eps"], a["n_all_eps"]) < 1e-9 and rel_mse(r["set"], a["n_set"]) < 1e-9
+
+
 def test_encoder(tiny_cfg):
     a, _ = load_golden("compressor_fwd_tiny")
     sd = load_golden("trainer_sample_tiny")[1]["c"]
