@@ -116,12 +116,11 @@ __device__ __forceinline__ void attn_tile(const char* Kt, const char* Vt, const 
 // per-wave dependency chain (LDS read -> 4 dependent MFMAs -> max -> exp -> cvt -> MFMAs, twice per tile) is what bounds the
 // other two kernels at 4 waves per SIMD (tools/dbg/attn_ablate.sh: 26.7 us with the loads compiled out, 23.4 us with the
 // compute compiled out, 35.9 us together); here the chain per tile is less than half as long.
+// The two halves of the joint tile step, separately callable: a caller that keeps TWO score accumulator pairs can issue the S^T MFMAs of key
+// tile t + 1 before the softmax of tile t (the matrix pipe then works under that wave's own softmax VALU: gemm_qkv_attn256_kernel).
 template <int DH>
-__device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
-                                                float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
-                                                const AttnLaneOffs<DH>& lo) {
-    constexpr int ROWB = DH * 2, ND = DH / 32, NS = DH / 16;
-    f32x16 s0, s1;
+__device__ __forceinline__ void attn_scores(const char* Kt, const bf16x8 (&qf)[DH / 16], f32x16& s0, f32x16& s1, const AttnLaneOffs<DH>& lo) {
+    constexpr int ROWB = DH * 2, NS = DH / 16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
@@ -131,6 +130,11 @@ __device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, 
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
     }
+}
+template <int DH>
+__device__ __forceinline__ void attn_softmax_pv(const char* Vt, f32x16& s0, f32x16& s1, f32x16 (&oacc)[DH / 32], float& m_run, float& l_run,
+                                                int kv0, int Nk, int hh, float c, const AttnLaneOffs<DH>& lo) {
+    constexpr int ROWB = DH * 2, ND = DH / 32;
     if (kv0 + 64 > Nk) {                                             // ragged tile: mask keys >= Nk
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -184,4 +188,14 @@ __device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, 
             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], oacc[d], 0, 0, 0);
         }
 }
+
+template <int DH>
+__device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
+                                                float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
+                                                const AttnLaneOffs<DH>& lo) {
+    f32x16 s0, s1;
+    attn_scores<DH>(Kt, qf, s0, s1, lo);
+    attn_softmax_pv<DH>(Vt, s0, s1, oacc, m_run, l_run, kv0, Nk, hh, c, lo);
+}
+
 

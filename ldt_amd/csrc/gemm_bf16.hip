@@ -1063,9 +1063,27 @@ __global__ __launch_bounds__(512) void gemm_qkv_attn256_kernel(const GemmArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
             float m_run = -INFINITY, l_run = 0.f;
-#pragma unroll 1
-            for (int t = 0; t < 4; ++t)
-                attn_tile_joint<64>(kvb + t * 8192, kvb + 32768 + t * 8192, qf, oacc, m_run, l_run, t * 64, 256, hh, a.attn_scale_log2e, lo);
+            // software-pipelined over the four key tiles: the S^T MFMAs of tile t + 1 are issued before the softmax of tile t, so the matrix
+            // pipe works under this wave's own softmax VALU (two score accumulator pairs; same math and summation order per tile)
+            f32x16 sa0, sa1, sb0, sb1;
+            const char* Kt = kvb;
+            const char* Vt = kvb + 32768;
+            const float csc = a.attn_scale_log2e;
+            attn_scores<64>(Kt, qf, sa0, sa1, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_scores<64>(Kt + 8192, qf, sb0, sb1, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<64>(Vt, sa0, sa1, oacc, m_run, l_run, 0, 256, hh, csc, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_scores<64>(Kt + 2 * 8192, qf, sa0, sa1, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<64>(Vt + 8192, sb0, sb1, oacc, m_run, l_run, 64, 256, hh, csc, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_scores<64>(Kt + 3 * 8192, qf, sb0, sb1, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<64>(Vt + 2 * 8192, sa0, sa1, oacc, m_run, l_run, 128, 256, hh, csc, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<64>(Vt + 3 * 8192, sb0, sb1, oacc, m_run, l_run, 192, 256, hh, csc, lo);
             // O / l through this wave's own q rows (dead: the fragments are in registers), whole rows out
             char* ost = stage_base + q0 * 128;
             const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
