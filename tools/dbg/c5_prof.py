@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ldt_amd
-N = 60
+N = int(os.environ.get("PROF_STEPS", "60"))
 cfg = ldt_amd.airplane_config(latent_tokens=32, sample_N=N)
 torch.manual_seed(0)
 score = ldt_amd.Score(cfg.score); comp = ldt_amd.Compressor(cfg.compressor); comp.init()
