@@ -48,7 +48,9 @@ class Score(nn.Module):
         # (Latent_SDE_Trainer.py:144): it is accepted and checked against self.training in forward
         self.dropout = float(getattr(cfg, "dropout", 0.) or 0.)
         if not self.AdaLN:
-            raise NotImplementedError("AdaLN: False blocks (layers.py:221-223) are not built — no shipped YAML sets it")
+            raise NotImplementedError("AdaLN: False blocks (layers.py:221-223) are not built: upstream adds pos_embedding(c) of shape (B, 1, C) to "
+                                      "the channel-first (B, C, N) activations without the transpose its AdaLN branch applies, which only "
+                                      "broadcasts when tokens == hidden_size — no shipped YAML sets it")
         if self.num_blocks > MAX_BLOCKS:
             raise ValueError("num_blocks > %d" % MAX_BLOCKS)
         D = self.hidden_size
