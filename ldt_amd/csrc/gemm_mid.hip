@@ -958,8 +958,18 @@ bool ldt_gemm_mid_qkv_attn_try(const GemmArgs* a_in, int tokens, int head_dim, b
     if (!on || !mid_env() || tokens != 32 || head_dim != 64 || !a_in->attn_o) return false;
     const GemmArgs& g = *a_in;
     if (g.N % 192 != 0 || (g.N / 3) % 64 != 0 || g.M % 128 != 0 || g.K % MID_BK != 0 || g.K / MID_BK < MidCfg<128, 192>::NS + 2) return false;
+    // the regime of this family (mid_shape_for): at most two rounds of workgroups — of the workgroups this launch may use when a sub-batch
+    // stream caps its grids (a->max_wgs); larger batches (B >= 256 at 16 heads) stay with the persistent 256^2 GEMM + the resident
+    // attention kernel.  No lower bound: a small batch saves a launch here and has nothing to lose to a bigger tile.
+    const long wgs = (long)(g.M / 128) * (g.N / 192);
+    const long cus = g.max_wgs > 0 && g.max_wgs < LDT_NUM_CUS ? g.max_wgs : LDT_NUM_CUS;
+    if (wgs > 2 * cus) return false;
     if (folded && (g.stats_parts > 32 || g.stats_parts * 32 != g.K || !g.stats_in || !g.fold_S || !g.fold_C)) return false;
-    if (!ldt_aligned16(g.attn_o) || (g.bias && !ldt_aligned16(g.bias)) || g.ldx % 8 != 0 || g.ldw % 8 != 0) return false;
+    // the argument checks of ldt_gemm_launch / ldt_gemm_lnfold_launch, which this route runs ahead of (a violation returns false:
+    // the generic path then reports it)
+    if (!g.X || !g.W || !ldt_aligned16(g.X) || !ldt_aligned16(g.W) || g.ldx < g.K || g.ldw < g.K || g.ldx % 8 != 0 || g.ldw % 8 != 0) return false;
+    if (!ldt_aligned16(g.attn_o) || (g.bias && !ldt_aligned16(g.bias))) return false;
+    if (folded && (!ldt_aligned16(g.stats_in) || !ldt_aligned16(g.fold_S) || !ldt_aligned16(g.fold_C) || g.fold_step_stride % 4 != 0)) return false;
     GemmArgs a = g;
     a.col_major = 1;
     *status = folded ? mid_qkv_attn_launch<MID_FOLD_CONSUMER>(a, stream) : mid_qkv_attn_launch<MID_FOLD_NONE>(a, stream);
@@ -975,7 +985,9 @@ bool ldt_gemm_mid_q_xattn_try(const GemmArgs* a_in, int tokens, int cond_tokens,
     if (!on || !mid_env() || tokens != 32 || cond_tokens != 32 || head_dim != 64 || !g.attn_o || !g.attn_k || !g.attn_v) return false;
     if (g.N % 64 != 0 || g.M % 64 != 0 || g.K % MID_BK != 0 || g.K / MID_BK < 2) return false;
     const long wgs = (long)(g.M / 64) * (g.N / 64);
-    if (wgs < 48 || wgs > 2 * LDT_NUM_CUS) return false;
+    const long cus = g.max_wgs > 0 && g.max_wgs < LDT_NUM_CUS ? g.max_wgs : LDT_NUM_CUS;
+    if (wgs < 48 || wgs > 2 * cus) return false;
+    if (!g.X || !g.W || !ldt_aligned16(g.X) || !ldt_aligned16(g.W) || g.ldx < g.K || g.ldw < g.K) return false;
     if (!ldt_aligned16(g.attn_o) || !ldt_aligned16(g.attn_k) || !ldt_aligned16(g.attn_v) || g.attn_ldkv % 8 != 0 || g.attn_kv_batch_stride % 8 != 0 ||
         (g.bias && !ldt_aligned16(g.bias)) || g.ldx % 8 != 0 || g.ldw % 8 != 0)
         return false;

@@ -392,6 +392,24 @@ class Score(nn.Module):
               "ldt_score_forward")
         return out
 
+    @torch.no_grad()
+    def forward_table_row(self, x, step_index, mod, fold=None):
+        """One Score evaluation reading row `step_index` of a MULTI-step batch-shared AdaLN table `mod` [n, n_mod] (and of its
+        LN-folding table `fold` [n, ...] when given) — exactly how step `step_index` of `ldt_sample_loop` addresses them
+        (base + step * stride, the step in device memory).  The parity tests use it to check the 1000-row tables the headline
+        config builds at rows far from 0 (tests/test_gpu_fullsize.py::test_fullsize_teacher_forced_rows_of_1000_step_tables)."""
+        if not x.is_cuda:
+            raise RuntimeError("Score.forward_table_row: x is on %s; the HIP path has no CPU fallback" % x.device)
+        B, T, z = x.shape
+        assert z == self.z_dim and mod.shape[1] == self.n_mod and 0 <= int(step_index) < mod.shape[0]
+        x = x.contiguous().float()
+        step = torch.full((1,), int(step_index), dtype=torch.int32, device=x.device)
+        plan = self.plan(B, T, mod, self.n_mod, 0, fold=fold)
+        out = torch.empty_like(x)
+        check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), step.data_ptr(), ops.stream_ptr()),
+              "ldt_score_forward")
+        return out
+
     def _forward_unet(self, x, t, label, condition):
         """`unet: True` variant (score.py:138-146): num_blocks//2 up blocks whose outputs are kept, a mid block, then
         num_blocks//2 down blocks on cat(x, skip) (width 2*hidden -> hidden, conv shortcut, adaLN1/adaLN2).  Host-driven:

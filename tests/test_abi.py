@@ -46,3 +46,60 @@ def test_argument_errors_are_reported_not_crashed(built):
     assert rc == -1 and b"null" in lib.ldt_last_error()
     with pytest.raises(built.LdtHipError):
         built.check(rc, "ldt_gemm_bf16")
+
+
+def test_no_export_outside_the_header(built):
+    """Every `ldt_*` symbol the shared library exports is declared in include/ldt_hip.h (a leftover experiment object linked into the .so
+    would show up here: VERDICT r4 item 9)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ldt_")})
+    assert exported == _header_functions(), sorted(set(exported) ^ set(_header_functions()))
+
+
+def test_library_links_exactly_the_present_sources(built):
+    """build.sh links one object per csrc/*.hip and nothing else (orphan objects are deleted, never linked)."""
+    import glob
+    csrc = os.path.join(ROOT, "ldt_amd", "csrc")
+    srcs = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(csrc, "*.hip")))
+    objs = sorted(os.path.basename(f)[:-2] for f in glob.glob(os.path.join(csrc, "build", "*.o")))
+    assert objs == srcs
+
+
+def _lint():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "ldt_amd", "csrc", "isa_lint.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_isa_lint_passes_on_the_built_library(built):
+    """The hand-counted waits / asm loads / main-loop -> epilogue fence of the hot kernels are what was audited (csrc/isa_lint.py;
+    build.sh runs the same check and fails the build on a violation)."""
+    L = _lint()
+    fps, errs, nk = L.analyse(built.LIB_PATH)
+    assert not errs, errs[:5]
+    gold = __import__("json").load(open(L.SIG_FILE))["kernels"]
+    assert fps == gold and len(fps) > 50 and nk > 100
+    assert L.analyse.tally.get("covered", 0) >= 100 and not L.analyse.tally.get("open") and not L.analyse.tally.get("violation")
+
+
+def test_isa_lint_catches_what_it_is_for():
+    """Negative controls on synthetic instruction streams: a copy of an asm-loaded register ahead of the wait, a wait that does not
+    cover, a changed vmcnt immediate in the fingerprint, an LDS read between the last MFMA and the epilogue fence, a missing fence."""
+    L = _lint()
+    mk = lambda lines: [L.Ins(t.split()[0], t, 0x100 + 4 * i, False) for i, t in enumerate(lines)]
+    ok = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "global_load_lds_dwordx4 v[6:7], off", "s_waitcnt vmcnt(1)", "v_add_f32 v8, v4, v5"])
+    t = {}
+    assert L.check_asm_load_safety("k", ok, t, "global_load_dwordx2") == [] and t == {"covered": 1}
+    moved = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "v_mov_b32 v9, v4", "s_waitcnt vmcnt(0)"])
+    assert len(L.check_asm_load_safety("k", moved, {}, "global_load_dwordx2")) == 1
+    short = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "global_load_lds_dwordx4 v[6:7], off", "s_waitcnt vmcnt(2)", "s_endpgm"])
+    assert any("no covering" in e for e in L.check_asm_load_safety("k", short, {}, "global_load_dwordx2"))
+    assert L.fingerprint(ok) == "L D W1" and L.fingerprint(short) == "L D W2"
+    fence = ["v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]"] + ["s_nop 15"] * 4 + ["ds_read_b128 v[0:3], v20"]
+    assert L.check_mfma_c_hazard("k", mk(fence)) == []
+    slipped = ["v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]", "ds_read_b128 v[0:3], v20"] + ["s_nop 15"] * 4
+    assert len(L.check_mfma_c_hazard("k", mk(slipped))) == 1
+    assert len(L.check_mfma_c_hazard("k", mk(fence[:1] + fence[5:]))) == 1

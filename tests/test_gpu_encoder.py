@@ -230,6 +230,13 @@ def test_compressor_rng_modes(tiny_cfg):
     assert torch.equal(torch.get_rng_state(), s0)
 
 
+def cc_gelu(cc):
+    import copy
+    c = copy.deepcopy(cc)
+    c.decoder_act = "gelu"
+    return c
+
+
 def test_compressor_variants_golden(tiny_cfg):
     """`decoder_act` (the decoder blocks' LayerNorm -> activation -> projection path: ldt_block_activation), `ActNorm: ~` and the dead
     `AdaLN: False` flag vs outputs captured from the reference (tests/golden/compressor_variants.npz)."""
@@ -248,6 +255,20 @@ def test_compressor_variants_golden(tiny_cfg):
         assert dec.shape == a[tag + "_points"].shape and rel_mse(dec.cpu(), a[tag + "_points"]) < 1e-4, tag
         r = comp(a["pts"].cuda(), post_noise=list(a[tag + "_post_noise"]))
         assert rel_mse(r["all_eps"].cpu(), a[tag + "_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a[tag + "_set"]) < 1e-3, tag
+    # the two activations of get_activation (tools/utils.py:104-124) the captured fixture does not hold — SELU and rrelu's eval form —
+    # against the oracle (pinned to the reference through the four above): same kernel slot, other constants
+    from oracle import ldt_oracle as O
+    for act in ("selu", "rrelu"):
+        ca = copy.deepcopy(cc); ca.decoder_act = act
+        comp = ldt_amd.Compressor(ca)
+        comp.load_state_dict(sds["w"], strict=True)
+        comp = comp.cuda(); comp.init()
+        dec = comp.sample((2, 64), given_eps=a["given_eps"].cuda())
+        with torch.no_grad():
+            ref = O.compressor_decode({k: v.float() for k, v in sds["w"].items()}, ca, a["given_eps"])
+            ref_g = O.compressor_decode({k: v.float() for k, v in sds["w"].items()}, cc_gelu(cc), a["given_eps"])
+        assert rel_mse(dec.cpu(), ref) < 1e-4, act
+        assert rel_mse(ref, ref_g) > 1e-3, act                                   # the activation matters in this fixture
     cn = copy.deepcopy(cc); cn.ActNorm, cn.AdaLN = None, False
     comp = ldt_amd.Compressor(cn)
     comp.load_state_dict({k: v for k, v in sds["w"].items() if not k.startswith("conv_in.")}, strict=True)

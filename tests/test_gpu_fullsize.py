@@ -125,6 +125,119 @@ def test_c1_exact_free_running(full):
     assert rel_mse(tr.compressor.sample((B, cfg.data.tr_max_sample_points), given_eps=zl.cuda()).cpu(), ref_dec) < 1e-4
 
 
+def test_fullsize_teacher_forced_rows_of_1000_step_tables(full):
+    """The headline config's own tables (BASELINE configs[1]: N = 1000): the 1000-row AdaLN table (598 MB) and LN-folding table
+    (1.38 GB) that `sample_discrete` builds with the 128 x 128 fp32 MFMA tile (N <= 100 takes the skinny tile), addressed at
+    rows 0 / 500 / 999 through the step counter exactly as step i of the fused loop does (base + i * stride).  B = 64 x T = 256
+    teacher-forced forwards on the LN-folded 256^2 path at latents of the scale the loop has there (rms 1 / 20 / 300), the first 4
+    samples against the oracle evaluated at t_i; the AdaLN rows themselves against the oracle's fp32 Linear(SiLU(TimeEmbedding)).
+    Reference: diffusion/diffusion_continuous.py:238,243-244 (timesteps), model/layers.py:14-41,214 (rows)."""
+    O, cfg, score = full["O"], full["cfg"], full["score"]
+    B, T, z, N, nb, D = 64, 256, cfg.score.z_dim, 1000, 4, cfg.score.hidden_size
+    ts = torch.linspace(1.0, 1e-6, N)
+    _, mod = score.time_table(ts.cuda())
+    assert mod.shape == (N, score.n_mod) and score.can_fold(B, T)
+    fold = score.fold_table(mod)
+    assert fold.shape[0] == N
+    g = torch.Generator().manual_seed(1000)
+    worst = 0.0
+    for row, scale in ((0, 1.0), (500, 20.0), (999, 300.0)):
+        t_i = ts[row:row + 1]
+        c_ref = O.time_embedding(full["sd_s"], "TimeEmbedding", t_i, cfg.score.t_dim // 4)
+        sc_ref = torch.nn.functional.silu(c_ref)
+        for l in (0, 11, 23):
+            ref_rows = O.linear(full["sd_s"], "Transformer.%d.adaLN.1" % l, sc_ref)
+            assert rel_mse(mod[row:row + 1, l * 6 * D:(l + 1) * 6 * D].cpu(), ref_rows) < 1e-10, (row, l)
+        assert rel_mse(mod[row:row + 1, -2 * D:].cpu(), O.linear(full["sd_s"], "ln_out.adaLN.1", sc_ref)) < 1e-10
+        x = torch.randn(B, T, z, generator=g) * scale
+        out = score.forward_table_row(x.cuda(), row, mod, fold)
+        out_ln = score.forward_table_row(x.cuda(), row, mod, None)          # the LayerNorm-kernel path on the same rows
+        with torch.no_grad():
+            ref = O.score_forward(full["sd_s"], cfg.score, x[:nb], t_i.expand(nb))
+        e_f, e_u = rel_mse(out[:nb].cpu(), ref), rel_mse(out_ln[:nb].cpu(), ref)
+        print("row %d of the 1000-step tables (t = %.6f, |x| ~ %g): folded %.3e, LayerNorm kernels %.3e" % (row, float(t_i), scale, e_f, e_u))
+        assert e_f < 1e-4 and e_u < 1e-4, (row, e_f, e_u)
+        worst = max(worst, e_f)
+    del fold, mod
+
+
+def test_n1000_free_running_production_width(full):
+    """The headline's own LENGTH: N = 1000 free-running ancestral steps at the production width (hidden 1024 x 24 blocks) through
+    Trainer.sample with injected x0 / per-step noise against the CPU oracle — T = 32 tokens, B = 2 shapes (about 1.5 min of CPU):
+    1000-row tables, step-indexed strides up to 999, a 1000-replay hipGraph, ten times the error accumulation of config C1.
+    Per-step relative MSE of the latents (from the loop's trajectory dump) and the final latents <= 1e-4.
+    Reference: diffusion/diffusion_continuous.py:152-162,231-258; trainer/Latent_SDE_Trainer.py:143-165."""
+    import time
+    import ldt_amd
+    O, score = full["O"], full["score"]
+    B, T, N = 2, 32, 1000
+    cfg = ldt_amd.airplane_config(latent_tokens=T, sample_N=N)
+    z = cfg.score.z_dim
+    torch.manual_seed(4)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    comp.init()
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    x0, noises = O.draw_noises(4321, B, T, z, N)
+    traj = []
+    pts, eps = tr.sample(B, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    assert traj[0].shape == (N, B, T, z) and pts.shape == (B, cfg.data.tr_max_sample_points, 3)
+    sde = O.VPSDE(cfg.sde)
+    fn = O.score_fn_from_model(sde, lambda xx, tt: O.score_forward(full["sd_s"], cfg.score, xx, tt))
+    rec = []
+    t0 = time.time()
+    with torch.no_grad():
+        ref_eps = O.sample_discrete(sde, fn, x0, noises, N, record=rec,
+                                    progress=lambda i: print("  oracle N=1000 step %d  %.0f s" % (i + 1, time.time() - t0), flush=True)
+                                    if (i + 1) % 100 == 0 else None)
+    xs = traj[0].cpu()
+    curve = [rel_mse(xs[i], rec[i][3]) for i in range(N)]
+    e_fin = rel_mse(eps.cpu(), ref_eps)
+    print("N = 1000 free-running, hidden 1024 x 24 blocks, B = %d, T = %d: per-step max %.3e (step %d), steps 0/499/999 %.3e / %.3e / %.3e, "
+          "final latents %.3e (rms %.1f)" % (B, T, max(curve), curve.index(max(curve)), curve[0], curve[499], curve[999], e_fin,
+                                             float(ref_eps.pow(2).mean().sqrt())))
+    assert max(curve) < 1e-4, (max(curve), curve.index(max(curve)))
+    assert e_fin < 1e-4
+
+
+def test_c1_shape_well_conditioned_fixed_bars(full):
+    """End to end at the production width with FIXED bars: config C1's shape (B = 4, T = 256, N = 100, ancestral, decode to 2048
+    points) on the well-conditioned fixture of oracle/fixtures.py — the seeded Score with ln_out.ln.weight += pinv(ln_in.weight),
+    which keeps the latents at rms 0.1-2 through the reverse SDE (the plain seeded weights inflate them to ~400, where the decoder
+    is ill-conditioned in fp32 already) — through Trainer.sample with injected noise against the oracle:
+    every step and the final latents <= 1e-4, decoded points <= 1e-3, Chamfer / mean squared radius <= 1e-3.
+    Reference: trainer/Latent_SDE_Trainer.py:143-165; diffusion/diffusion_continuous.py:152-162,231-258."""
+    import time
+    import ldt_amd
+    from oracle.fixtures import condition_score_head
+    O, cfg = full["O"], full["cfg"]
+    B, N, T, z = 4, 100, 256, cfg.score.z_dim
+    sd_w = condition_score_head(full["sd_s"])
+    score = ldt_amd.Score(cfg.score)
+    score.load_state_dict(sd_w, strict=True)
+    tr = ldt_amd.Trainer(cfg, score, full["comp"], "cuda:0")
+    x0, noises = O.draw_noises(99, B, T, z, N)
+    traj = []
+    pts, eps = tr.sample(B, x0=x0, noise=torch.stack(noises), trajectory=traj)
+    rec = []
+    t0 = time.time()
+    with torch.no_grad():
+        ref_pts, ref_eps = O.trainer_sample(sd_w, full["sd_c"], cfg, x0, noises, record=rec,
+                                            progress=lambda i: print("  oracle (well-conditioned C1) step %d/%d  %.0f s" % (i + 1, N, time.time() - t0), flush=True)
+                                            if (i + 1) % 10 == 0 else None)
+    xs = traj[0].cpu()
+    curve = [rel_mse(xs[i], rec[i][3]) for i in range(N)]
+    rms = [float(rec[i][3].pow(2).mean().sqrt()) for i in (0, 50, 98, 99)]
+    r2 = (ref_pts ** 2).sum(-1).mean(1)
+    cd = float((O.chamfer_cd(pts.cpu(), ref_pts) / r2).max())
+    e_fin, e_pts = rel_mse(eps.cpu(), ref_eps), rel_mse(pts.cpu(), ref_pts)
+    print("well-conditioned C1 (latent rms at steps 0/50/98/99: %.2f / %.2f / %.2f / %.2f): per-step max %.3e, final latents %.3e, "
+          "points %.3e, Chamfer / r^2 %.3e" % (rms[0], rms[1], rms[2], rms[3], max(curve), e_fin, e_pts, cd))
+    assert max(rms) < 10.0                                          # the fixture does what it is for
+    assert max(curve) < 1e-4, (max(curve), curve.index(max(curve)))
+    assert e_fin < 1e-4
+    assert e_pts < 1e-3 and cd < 1e-3
+
+
 @pytest.mark.parametrize("tokens", [256, 32])
 def test_compressor_fullsize_big_batch_vs_oracle(tokens):
     """BASELINE configs[3] shapes through the big-batch kernels (512 clouds per call: one-wave FPS, kNN candidate select, one-kernel

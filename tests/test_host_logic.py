@@ -497,17 +497,24 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     assert argv[argv.index("--master-port") + 1] == "29555"
     tail = argv[argv.index(os.path.join(ROOT, "bench.py")) + 1:]
     assert tail == ["--gpus", "2", "--steps", "3", "--warmup", "1"]              # same arguments, the launch flag dropped
-    calls = {}
+    calls = {"n": 0}
 
-    def fake_call(cmd, env=None):
-        calls["cmd"], calls["env"] = cmd, env
-        return 7
-    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    class FakeChild:                                         # first launch: the port was taken meanwhile -> one retry on a fresh port
+        def __init__(self, cmd, env=None, stderr=None, text=None):
+            calls["n"] += 1
+            calls["cmd"], calls["env"] = cmd, env
+            calls.setdefault("ports", []).append(cmd[cmd.index("--master-port") + 1])
+            self.stderr = iter(["RuntimeError: ... EADDRINUSE: address already in use\n"] if calls["n"] == 1 else ["rank 0 failed\n"])
+
+        def wait(self):
+            return 1 if calls["n"] == 1 else 7
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeChild)
     monkeypatch.setattr(bench.torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
     monkeypatch.delenv("RANK", raising=False)
     with pytest.raises(SystemExit) as ei:
         bench.main()
     assert ei.value.code == 7 and calls["cmd"][-2:] == ["--gpus", "2"] and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert calls["n"] == 2                                   # retried once (address in use), not again (an ordinary failure is relayed)
     c5 = bench.parse(["--config", "c5"])
     assert (c5.tokens, c5.batch_per_gpu) == (32, 32) and bench.parse([]).tokens == 256 and bench.parse([]).batch_per_gpu == 64
