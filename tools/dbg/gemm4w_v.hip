@@ -60,7 +60,31 @@ __global__ __launch_bounds__(256, 1) void gemm4w_v_kernel(const Args a) {
         : G4V_CLOBBERS, "memory", "scc", "vcc");
 
     // accumulator (k, p) = a[(k*8+p)*4 + r] = D[n = n0t + wn*128 + k*16 + lchk*4 + r][m = m0t + wm*128 + p*16 + lrow]
-    if (a.store) {
+    if (a.store == 2) {
+        // staged epilogue (the product kernels' form): 16 output rows x the wave's 128 columns per pass through 4.25 KiB of the wave's (idle)
+        // operand buffer, then 16 B per lane over whole 256-B row segments
+        char* reg = smem + wave * 8192;
+        constexpr int RS = 256 + 16;
+#define STAGE_TILE(k, p)                                                                          \
+    {                                                                                             \
+        float f0, f1, f2, f3;                                                                     \
+        ACC_READ(f0, ((k) * 8 + (p)) * 4 + 0); ACC_READ(f1, ((k) * 8 + (p)) * 4 + 1);             \
+        ACC_READ(f2, ((k) * 8 + (p)) * 4 + 2); ACC_READ(f3, ((k) * 8 + (p)) * 4 + 3);             \
+        const bf16x4 pk = {(bf16_t)f0, (bf16_t)f1, (bf16_t)f2, (bf16_t)f3};                       \
+        *reinterpret_cast<bf16x4*>(reg + lrow * RS + ((k) * 16 + lchk * 4) * 2) = pk;             \
+    }
+#define STAGE_PASS(p)                                                                                                              \
+    {                                                                                                                              \
+        STAGE_TILE(0, p) STAGE_TILE(1, p) STAGE_TILE(2, p) STAGE_TILE(3, p) STAGE_TILE(4, p) STAGE_TILE(5, p) STAGE_TILE(6, p) STAGE_TILE(7, p) \
+        bf16_t* o = a.Y + (long)(m0t + wm * 128 + (p) * 16) * a.N + n0t + wn * 128;                                               \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                                         \
+            const int row = it * 4 + (lane >> 4), ch = lane & 15;                                                                  \
+            const uint4 d = *reinterpret_cast<const uint4*>(reg + row * RS + ch * 16);                                             \
+            *reinterpret_cast<uint4*>(o + (long)row * a.N + ch * 8) = d;                                                           \
+        }                                                                                                                          \
+    }
+        STAGE_PASS(0) STAGE_PASS(1) STAGE_PASS(2) STAGE_PASS(3) STAGE_PASS(4) STAGE_PASS(5) STAGE_PASS(6) STAGE_PASS(7)
+    } else if (a.store) {
 #define STORE_TILE(k, p)                                                                          \
     {                                                                                             \
         float f0, f1, f2, f3;                                                                     \
@@ -94,7 +118,7 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&dx, hx.size() * 2 + pad); (void)hipMalloc(&dw, hw.size() * 2 + pad); (void)hipMalloc(&dy, (size_t)M * N * 2);
     (void)hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemset(dy, 0, (size_t)M * N * 2);
-    Args a{dx, dw, dy, M, N, K, 1};
+    Args a{dx, dw, dy, M, N, K, store == 2 ? 2 : 1};
     const int lds = 131072;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_v_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int tiles = (M / 256) * (N / 256);
