@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 19
+#define LDT_ABI_VERSION 20
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -357,6 +357,12 @@ typedef struct ldt_cond_args {
     float* c_buf;         /* [batch][t_dim]    scratch */
     float* mod_buf;       /* [batch][n_mod]    scratch; plan->mod must point here with mod_sample_stride = n_mod */
     int32_t t_dim, n_mod;
+    /* optional (both or neither): the stacked adaLN weights as a bf16 panel [n_mod][t_dim] and a bf16 scratch [batch][t_dim].  When
+     * given, the per-step rows are one bf16 MFMA GEMM (fp32 accumulation and bias) that streams 2 bytes per weight instead of 4 —
+     * the fp32 form is HBM-bound on its 4 n_mod t_dim bytes per step (BASELINE configs[4]: 604 MB, 9 % of a step).  Rows then carry
+     * bf16 operand rounding (relative MSE ~5e-6), like every token GEMM of the model. */
+    const void* w_ada_bf16;
+    void* c_buf_bf16;
 } ldt_cond_args;
 
 /* The whole reverse-SDE loop (pc_sampling, diffusion_continuous.py:231-258 with corrector None): n_steps x

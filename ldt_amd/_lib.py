@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 19
+ABI_VERSION = 20
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -44,7 +44,8 @@ class ScorePlan(C.Structure):
 
 class CondArgs(C.Structure):
     """Mirror of `ldt_cond_args` (include/ldt_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("temb", "extra", "w_ada", "b_ada", "c_buf", "mod_buf")] + [("t_dim", _i32), ("n_mod", _i32)]
+    _fields_ = ([(n, _vp) for n in ("temb", "extra", "w_ada", "b_ada", "c_buf", "mod_buf")] + [("t_dim", _i32), ("n_mod", _i32)] +
+                [("w_ada_bf16", _vp), ("c_buf_bf16", _vp)])
 
 
 # name -> argtypes; every symbol include/ldt_hip.h declares (tests/test_abi.py checks the two lists agree)

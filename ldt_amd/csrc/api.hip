@@ -431,10 +431,20 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
                         const float* noise, long noise_step_stride, long elem_offset, uint64_t seed, int* step_counter,
                         const ldt_cond_args* cond, float* x_traj, hipStream_t s) {
     if (cond) {                                                 // per-sample AdaLN rows of this step
-        TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, step_counter, p->batch, cond->t_dim, 1, s));   // c_buf = silu(c)
-        SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_NONE,
-                    LDT_ACT_NONE, p->batch, cond->n_mod, cond->t_dim};
-        TRY(ldt_sgemm_launch(&g, s));
+        TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, cond->c_buf_bf16, step_counter, p->batch, cond->t_dim, 1, s));   // c_buf = silu(c)
+        if (cond->w_ada_bf16) {                                 // bf16 weight panel: half the bytes of the HBM-bound row GEMM (fp32 accumulation + bias)
+            GemmArgs g{};
+            g.X = BF(cond->c_buf_bf16); g.ldx = cond->t_dim;
+            g.W = BF(cond->w_ada_bf16); g.ldw = cond->t_dim;
+            g.bias = cond->b_ada; g.out = cond->mod_buf; g.ldo = cond->n_mod;
+            g.M = p->batch; g.N = cond->n_mod; g.K = cond->t_dim;
+            g.max_wgs = p->gemm_wgs;
+            TRY(ldt_gemm_launch(EPI_F32, &g, s));
+        } else {
+            SgemmArgs g{cond->c_buf, cond->t_dim, cond->w_ada, cond->t_dim, cond->b_ada, cond->mod_buf, cond->n_mod, 0, LDT_ACT_NONE,
+                        LDT_ACT_NONE, p->batch, cond->n_mod, cond->t_dim};
+            TRY(ldt_sgemm_launch(&g, s));
+        }
     }
     TRY(score_forward_impl(p, x, eps_tmp, cond ? nullptr : step_counter, s, nullptr));
     const long n = (long)p->batch * p->tokens * p->z_dim;
@@ -450,6 +460,7 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
                                float* x_traj, int32_t use_graph, void* stream) {
     TRY(check_plan(p));
     LDT_REQUIRE(x && x_mean && eps_tmp && coef && step_counter && n_steps > 0, LDT_EARG, "sample_loop: null pointer / n_steps");
+    LDT_REQUIRE(!cond || !cond->w_ada_bf16 == !cond->c_buf_bf16, LDT_EARG, "sample_loop: w_ada_bf16 and c_buf_bf16 go together");
     LDT_REQUIRE(!cond || (cond->temb && cond->w_ada && cond->c_buf && cond->mod_buf && cond->mod_buf == p->mod &&
                           p->mod_sample_stride == cond->n_mod && cond->t_dim > 0), LDT_EARG,
                 "sample_loop: inconsistent conditioning block (plan->mod must be cond->mod_buf with sample stride n_mod)");

@@ -346,18 +346,21 @@ int ldt_sgemm_launch(const SgemmArgs* a, hipStream_t s) {
 
 // c[b][k] = silu?(temb[step][k] + extra[b][k])   (score.py:135: c = t_emb + l_emb | img condition; the SiLU that opens every AdaLN
 // Sequential — model/layers.py:172 — is applied here once so that the row GEMM behind it can stream its A operand by LDS-DMA), step from the device counter
-__global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __restrict__ extra, float* __restrict__ c,
+// `cb` (optional): the same rows rounded to bf16 — the A operand of the bf16-weight form of the row GEMM (ldt_cond_args.w_ada_bf16)
+__global__ void cond_rows_kernel(const float* __restrict__ temb, const float* __restrict__ extra, float* __restrict__ c, bf16_t* __restrict__ cb,
                                  const int* __restrict__ step_ptr, int batch, int t_dim, int silu_out) {
     const int step = step_ptr ? *step_ptr : 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < batch * t_dim; i += gridDim.x * blockDim.x) {
         const int k = i % t_dim;
         const float v = temb[(long)step * t_dim + k] + (extra ? extra[i] : 0.f);
-        c[i] = silu_out ? silu(v) : v;
+        const float o = silu_out ? silu(v) : v;
+        c[i] = o;
+        if (cb) cb[i] = (bf16_t)o;
     }
 }
-int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, int silu_out, hipStream_t s) {
+int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, void* c_bf16, const int* step_ptr, int batch, int t_dim, int silu_out, hipStream_t s) {
     LDT_REQUIRE(temb && c && batch > 0 && t_dim > 0, LDT_EARG, "cond_rows: bad arguments");
     int blocks = (batch * t_dim + 255) / 256; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(cond_rows_kernel, dim3(blocks), dim3(256), 0, s, temb, extra, c, step_ptr, batch, t_dim, silu_out);
+    hipLaunchKernelGGL(cond_rows_kernel, dim3(blocks), dim3(256), 0, s, temb, extra, c, reinterpret_cast<bf16_t*>(c_bf16), step_ptr, batch, t_dim, silu_out);
     return ldt_check_launch("cond_rows");
 }

@@ -149,4 +149,4 @@ int ldt_ln_linear_launch(const LnLinArgs* a, int C, hipStream_t st);
 int ldt_chamfer_pairwise_launch(const float* x, const float* y, int S, int R, int n, int m, float* cd, hipStream_t st);
 int ldt_emd_approx_launch(const float* x, const float* y, int S, int R, int n, int m, int pairwise, float* out, hipStream_t st);
 int ldt_fold_monitor_launch(const float* stats, int parts, long M, int K, float* out, hipStream_t s);   // samplers.hip
-int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, const int* step_ptr, int batch, int t_dim, int silu_out, hipStream_t s);
+int ldt_cond_rows_launch(const float* temb, const float* extra, float* c, void* c_bf16, const int* step_ptr, int batch, int t_dim, int silu_out, hipStream_t s);

@@ -205,6 +205,7 @@ class DiffusionBase:
                 extra, kv, S = model.condition_embedding(label, condition)            # per-sample rows, rebuilt every step
                 temb = model.time_embedding(ts.to(dev))
                 w_ada, b_ada = model.stacked_adaln()
+                w_ada_bf = model.stacked_adaln_bf16() if int(os.environ.get("LDT_ADALN_BF16", "1")) else None
             bounds = [B * i // streams for i in range(streams + 1)]
             jobs, keep = [], []
             fold = None
@@ -231,10 +232,11 @@ class DiffusionBase:
                     ex = None if extra is None else extra[lo:hi].contiguous()
                     kvs = None if kv is None else {l: t.view(B, S, -1)[lo:hi].reshape(Bs * S, -1) for l, t in kv.items()}
                     plan = model.plan(Bs, T, modb, 0, model.n_mod, kv_cond=kvs, cond_tokens=S, slot=i, gemm_wgs=wgs)
+                    c_bf = None if w_ada_bf is None else torch.empty((Bs, model.t_dim), dtype=torch.bfloat16, device=dev)
                     cond = CondArgs(temb.data_ptr(), ops._p(ex), w_ada.data_ptr(), b_ada.data_ptr(), c_buf.data_ptr(),
-                                    modb.data_ptr(), model.t_dim, model.n_mod)
+                                    modb.data_ptr(), model.t_dim, model.n_mod, ops._p(w_ada_bf), ops._p(c_bf))
                     cond_ref = ctypes.byref(cond)
-                    keep.append((ex, kvs, c_buf, modb, cond))
+                    keep.append((ex, kvs, c_buf, modb, cond, c_bf, w_ada_bf))
                 if nz is not None and streams > 1:
                     nz = nz.contiguous()                                              # [N, Bs, T, z] with step stride Bs*T*z
                 jobs.append((plan, xs, xm, eps_tmp, counter, nz, cond_ref, elem_offset + lo * int(np.prod(shape)), tj))

@@ -134,6 +134,17 @@ class Score(nn.Module):
                 P["b_ada"] = torch.cat([l.bias.detach().float() for l in lins], 0).contiguous()
         return P["w_ada"], P["b_ada"]
 
+    def stacked_adaln_bf16(self):
+        """The stacked adaLN weights as a bf16 panel [n_mod][t_dim] (ldt_cond_args.w_ada_bf16): the per-step per-sample AdaLN rows of
+        the conditional sampler are HBM-bound on their weights (BASELINE configs[4]: 604 MB fp32 per step, 163 us = 9 % of a step;
+        80 us as bf16 — profiles/r05_adaln_bf16_probe.txt), and bf16 operands with fp32 accumulation are what every token GEMM of the
+        model already runs on.  LDT_ADALN_BF16=0 keeps the fp32 SGEMM (the rows then equal the reference's fp32 Linear to 1e-12)."""
+        P = self.packed()
+        if "w_ada_bf16" not in P:
+            w_ada, _ = self.stacked_adaln()
+            P["w_ada_bf16"] = ops.cast_pad_bf16(w_ada, w_ada.shape[1])
+        return P["w_ada_bf16"]
+
     def time_embedding(self, t):
         """TimeEmbedding(t) only: t [n] -> c [n, t_dim] fp32 (model/layers.py:38-41)."""
         te = self.TimeEmbedding.mlp

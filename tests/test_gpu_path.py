@@ -62,10 +62,13 @@ def test_score_forward_conditioned_golden(env):
         env["score"](a["x"].cuda(), a["t"].cuda(), condition={"pts": pts})
 
 
-def test_conditioned_sampling_loop_vs_oracle(env):
+def test_conditioned_sampling_loop_vs_oracle(env, monkeypatch):
     """Fused conditional loop (per-sample AdaLN rows recomputed in C++ every step + cross-attention) == the
-    Python-driven loop == the oracle with the same condition, on injected noise."""
+    Python-driven loop == the oracle with the same condition, on injected noise — with the per-step rows from the fp32 SGEMM
+    (LDT_ADALN_BF16=0: equals the Python-driven loop, whose rows are fp32, to 1e-6) and from the bf16 weight panel (the default:
+    half the bytes of that HBM-bound GEMM; bf16 operand rounding like every token GEMM), both within the latent bar of the oracle."""
     O, tg, tr, cfg = env["O"], env["tg"], env["tr"], env["cfg"]
+    monkeypatch.setenv("LDT_ADALN_BF16", "0")
     a, _ = load_golden("score_tiny")
     pts_tm = a["pts_cond"][:2]; img = a["img_cond"][:2]                     # token-major [B,S,hidden] / [B,t_dim]
     cond_dev = (pts_tm.transpose(1, 2).contiguous().cuda(), img.cuda())
@@ -82,6 +85,12 @@ def test_conditioned_sampling_loop_vs_oracle(env):
     ref = O.sample_discrete(sde, fn, tg["x0"], list(tg["noises"]), cfg.sde.sample_N)
     assert rel_mse(fused.cpu(), ref) < TOL_LATENT
     assert rel_mse(fused.cpu(), tg["eps"]) > 1e-3                            # differs from the unconditional trajectory
+    monkeypatch.delenv("LDT_ADALN_BF16")                                     # the default: bf16 weight panel for the per-step rows
+    fused_bf = tr.SDE.sample_discrete(**kw, use_graph=0)
+    assert torch.equal(fused_bf, tr.SDE.sample_discrete(**kw, use_graph=1))
+    e_bf, e_32 = rel_mse(fused_bf.cpu(), ref), rel_mse(fused.cpu(), ref)
+    print("conditional loop vs oracle: fp32 AdaLN rows %.2e, bf16 weight panel %.2e" % (e_32, e_bf))
+    assert e_bf < TOL_LATENT and not torch.equal(fused_bf, fused)
 
 
 def test_label_conditioning_vs_oracle(tiny_cfg):
