@@ -552,10 +552,22 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
                "decode_rel_mse": rel(dg[:nb].cpu(), dec_ref), "tol": {"all_eps": 1e-4, "set": 1e-4, "decode": 1e-4}}
         par["pass"] = bool(par["fps_idx_equal"] and par["encode_all_eps_rel_mse"] < 1e-4 and par["encode_set_rel_mse"] < 1e-4 and par["decode_rel_mse"] < 1e-4)
 
-    def hb(bytes_, t):
+    def hb(bytes_, t, nq, nk):
+        """The kernel against the THREE floors of its launch: HBM (algorithmic bytes at 8 TB/s), the matrix pipe
+        (QK^T + PV flops at the dense bf16 peak) and VALU issue — per score one v_exp_f32 (8 issue cycles per wave-instruction,
+        MI355X_MICROARCH.md 'vector-instruction ISSUE cost') + half each of v_pk_fma (scale, - max), v_pk_add (row sum), v_cvt_pk_bf16
+        and v_max3 (4 cycles each): 16 cycles per 64 scores on one of the chip's 1024 SIMDs at the 2.4 GHz peak clock.  The largest
+        floor names the bound; `frac` = that floor / measured (the phases do not overlap perfectly: the sum of the three is the
+        no-overlap time)."""
         gbs = bytes_ / t / 1e9
-        return {"us": round(t * 1e6, 1), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                "bound": "hbm", "bytes_per_launch": bytes_, "clouds_per_launch": Bm}
+        scores = float(Bm) * H * nq * nk
+        fl = {"hbm_us": bytes_ / (PEAK_HBM_GBS * 1e9) * 1e6, "mfma_us": 4.0 * scores * dh / (PEAK_BF16_TFLOPS * 1e12) * 1e6,
+              "valu_issue_us": scores / 64.0 * 16.0 / 1024.0 / 2.4e9 * 1e6}
+        bound = max(fl, key=fl.get)
+        return {"us": round(t * 1e6, 1), "bound": bound[:-3], "floors_us": {k: round(v, 1) for k, v in fl.items()},
+                "frac": round(fl[bound] / (t * 1e6), 4), "no_overlap_sum_us": round(sum(fl.values()), 1),
+                "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": bytes_},
+                "scores_per_launch": scores, "clouds_per_launch": Bm}
 
     return {"workload": "BASELINE configs[3]: Compressor encode+decode only, batch %d, 2048 pts <-> %d tokens, 1 GPU" % (batch, T),
             "encode_clouds_per_s": round(batch / t_enc, 1), "decode_clouds_per_s": round(batch / t_dec, 1),
@@ -568,7 +580,7 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
             "decode_unfused_lower_bound": {"what": "7 kernels per block each reading + writing the fp32 (2048 x %d) set at 8 TB/s" % d,
                                            "clouds_per_s": round(unfused_clouds_s, 1), "bytes_per_cloud": unfused_bytes,
                                            "measured_over_bound": round(batch / t_dec / unfused_clouds_s, 3)},
-            "cross_attn_q2048_kvT": hb(b1, t1), "cross_attn_qT_kv2048": hb((2 * Bm * T * d + 2 * Bm * 2048 * d) * 2.0, t2),
+            "cross_attn_q2048_kvT": hb(b1, t1, 2048, T), "cross_attn_qT_kv2048": hb((2 * Bm * T * d + 2 * Bm * 2048 * d) * 2.0, t2, T, 2048),
             "parity": par,
             "cpu_baseline": {"encode_clouds_per_s": round(nb / t_ce, 3), "decode_clouds_per_s": round(nb / t_cd, 3), "cores": host_cores(),
                              "kind": "port", "sample": "oracle compressor_encode / compressor_decode on %d of the %d clouds" % (nb, batch)}}
