@@ -18,8 +18,8 @@ def load(d, counter):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                name = re.sub(r"^void ", "", r["Kernel_Name"])
-                name = re.sub(r"\(.*$", "", name).replace("(anonymous namespace)::", "")
+                name = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "")
+                name = re.sub(r"\(.*$", "", name)
                 out[name].append(float(r["Counter_Value"]))
     return out
 

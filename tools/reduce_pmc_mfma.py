@@ -17,7 +17,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(pdir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = re.sub(r"^void ", "", r["Kernel_Name"])
-        name = re.sub(r"\(.*$", "", name).replace("(anonymous namespace)::", "")
+        name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows, out = [], {}
 for k, d in sorted(acc.items()):
