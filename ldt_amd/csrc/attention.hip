@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
 // query blocks with no further workgroup barrier — K/V are fetched once per head instead of once per query
 // block, and the per-tile barrier/restage of the streaming kernel disappears.  Same math, same layouts.
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArgs a, int ntl) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArgs a, int ntl, int qsplit) {
     constexpr int KT = 64;
     constexpr int ROWB = DH * 2;
     constexpr int CH = ROWB / 16;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
     char* Vs = rsmem + ntl * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.x;
+    const int bh = blockIdx.x / qsplit, part = blockIdx.x % qsplit;
     const int b = bh / a.H, head = bh % a.H;
     char* ost = rsmem + 2 * ntl * TILE + wave * (32 * ROWB);
     const bf16_t* Qb = a.Q + (long)b * a.q_batch_stride + head * DH;
@@ -276,7 +276,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
     AttnLaneOffs<DH> lo;
     lo.init(lane);
     const int nqb = (a.Nq + 127) / 128;
-    for (int qb = 0; qb < nqb; ++qb) {
+    // `qsplit` workgroups share a head's query blocks (each loads the head's K / V again: 32-64 KB from L2): with few heads in the launch
+    // (128 clouds x 4 heads = 512) one workgroup per head left two waves per SIMD, each serialised on its own MFMA -> softmax -> MFMA chain
+    // over 16 query blocks (round 5; prefetching the next block's Q instead measured 5 % SLOWER: profiles/r05_attention_resident_ab.txt)
+    const int qb_lo = (int)((long)nqb * part / qsplit), qb_hi = (int)((long)nqb * (part + 1) / qsplit);
+    for (int qb = qb_lo; qb < qb_hi; ++qb) {
         const int q0 = qb * 128 + wave * 32;
         if (q0 >= a.Nq) continue;                                       // wave-uniform; no barrier below
         bf16x8 qf[NS];
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_head_kernel(const AttnArgs a)
 // workgroup owns a (cloud, head): K/V go to LDS once, each wave keeps its C/4 output channels of Wo as register fragments, and
 // the workgroup walks the head's query blocks (no barrier inside the attention; two per block around the 8 KB output stage).
 template <int H>   // heads: C = 32 H channels (2 or 4)
-__global__ __launch_bounds__(256, 4) void attn_oproj_resident_kernel(const AttnArgs a, int ntl) {
+__global__ __launch_bounds__(256, 3) void attn_oproj_resident_kernel(const AttnArgs a, int ntl) {   // (3 waves per SIMD: the prefetched Q / residual registers do not fit 128 VGPRs)
     constexpr int DH = 32, KT = 64, ROWB = DH * 2, CH = ROWB / 16, NS = DH / 16, TILE = KT * ROWB;
     constexpr int C = H * DH, R = 128 / H, NT = C / 64, RT = R / 16, rowb = C * 2;
     extern __shared__ __attribute__((aligned(16))) char rsmem[];       // [K: ntl tiles][V: ntl tiles][O stage: R rows x C bf16 = 8 KB]
@@ -505,16 +509,35 @@ __global__ __launch_bounds__(256, 4) void attn_oproj_resident_kernel(const AttnA
     AttnLaneOffs<DH> lo;
     lo.init(lane);
     const int nqb = (a.Nq + 127) / 128;
-    for (int qb = 0; qb < nqb; ++qb) {
-        const int q0 = qb * 128 + wave * 32;
-        bf16x8 qf[NS];
-        {
-            int qrow = q0 + r;
-            qrow = qrow < a.Nq ? qrow : a.Nq - 1;                           // rows past the end: computed, never stored
-            const bf16_t* qp = Qb + (long)qrow * a.ldq + 8 * hh;
+    // Round 5: nothing a query block needs from global memory is requested at the point of use any more.  The Q fragments of block
+    // qb + 1 and the fp32 residual rows of block qb (read-modify-written by the epilogue) are requested at the head of block qb and land
+    // under its attention; the projection bias is loaded once.  Before, each of the up to 16 blocks of a workgroup opened on a
+    // dependent Q round trip and closed on a dependent residual round trip (~1.5 us each beside ~3 us of work).
+    auto load_q = [&](int qb, bf16x8 (&q)[NS]) {
+        int qrow = qb * 128 + wave * 32 + r;
+        qrow = qrow < a.Nq ? qrow : a.Nq - 1;                               // rows past the end: computed, never stored
+        const bf16_t* qp = Qb + (long)qrow * a.ldq + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-        }
+        for (int s = 0; s < NS; ++s) q[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    };
+    f32x4 b4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b4[nt] = *reinterpret_cast<const f32x4*>(a.bo + n0 + nt * 16 + lq * 4);
+    bf16x8 qf[NS], qn[NS];
+    load_q(0, qf);
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int qb0 = qb * 128;
+        const int valid_rows = (min(128, a.Nq - qb0)) / H;                // Nq % H == 0 (checked by the launcher)
+        const long xrow0 = (long)b * a.Nq + ((long)head * a.Nq + qb0) / H;
+        f32x4 xpre[NT][RT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int orow = rt * 16 + lrow, orc = orow < valid_rows ? orow : valid_rows - 1;   // clamped, never branched; rows past the end are not stored
+                xpre[nt][rt] = *reinterpret_cast<const f32x4*>(a.X + (xrow0 + orc) * a.ldx + n0 + nt * 16 + lq * 4);
+            }
+        load_q(qb + 1 < nqb ? qb + 1 : qb, qn);
         f32x16 oacc[1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[0][i] = 0.f;
@@ -552,9 +575,6 @@ __global__ __launch_bounds__(256, 4) void attn_oproj_resident_kernel(const AttnA
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) pacc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], of[rt], pacc[nt][rt], 0, 0, 0);
         }
-        const int qb0 = qb * 128;
-        const int valid_rows = (min(128, a.Nq - qb0)) / H;                // Nq % H == 0 (checked by the launcher)
-        const long xrow0 = (long)b * a.Nq + ((long)head * a.Nq + qb0) / H;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -562,18 +582,19 @@ __global__ __launch_bounds__(256, 4) void attn_oproj_resident_kernel(const AttnA
                 const int orow = rt * 16 + lrow, ch = n0 + nt * 16 + lq * 4;
                 if (orow >= valid_rows) continue;
                 float* xp = a.X + (xrow0 + orow) * a.ldx + ch;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bo + ch);
-                f32x4 xo = *reinterpret_cast<const f32x4*>(xp);
+                f32x4 xo = xpre[nt][rt];
                 if (a.gate) {
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.gate + (long)b * a.gate_sample_stride + ch);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xo[jj] += g4[jj] * (pacc[nt][rt][jj] + b4[jj]);
+                    for (int jj = 0; jj < 4; ++jj) xo[jj] += g4[jj] * (pacc[nt][rt][jj] + b4[nt][jj]);
                 } else {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xo[jj] += pacc[nt][rt][jj] + b4[jj];
+                    for (int jj = 0; jj < 4; ++jj) xo[jj] += pacc[nt][rt][jj] + b4[nt][jj];
                 }
                 *reinterpret_cast<f32x4*>(xp) = xo;
             }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = qn[s];
         __syncthreads();                                                    // the stage is rewritten by the next query block
     }
 }
@@ -583,7 +604,13 @@ static int launch_resident(const AttnArgs* a, hipStream_t s) {
     const int ntl = (a->Nk + 63) / 64;
     const size_t lds = (size_t)2 * ntl * 64 * DH * 2 + 4 * 32 * DH * 2;
     LDT_ENSURE_LDS(&attn_fwd_resident_kernel<DH>, 81920, "attention");
-    hipLaunchKernelGGL(attn_fwd_resident_kernel<DH>, dim3((unsigned)(a->B * a->H)), dim3(256), lds, s, *a, ntl);
+    // query blocks of a head over `qsplit` workgroups until the launch has ~4 workgroups per CU (or one block each)
+    static const int qs_env = getenv("LDT_ATTN_QSPLIT") ? atoi(getenv("LDT_ATTN_QSPLIT")) : 0;      // tools/dbg
+    const long heads = (long)a->B * a->H, nqb = (a->Nq + 127) / 128;
+    long qsplit = qs_env > 0 ? qs_env : (4L * LDT_NUM_CUS + heads - 1) / heads;
+    qsplit = qsplit < 1 ? 1 : (qsplit > nqb ? nqb : qsplit);
+    LDT_REQUIRE(heads * qsplit < (1L << 31), LDT_ESHAPE, "attention: grid too large");
+    hipLaunchKernelGGL(attn_fwd_resident_kernel<DH>, dim3((unsigned)(heads * qsplit)), dim3(256), lds, s, *a, ntl, (int)qsplit);
     return ldt_check_launch("attn_fwd_resident");
 }
 
