@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 20
+#define LDT_ABI_VERSION 21
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -177,6 +177,18 @@ enum ldt_block_act { LDT_BACT_NONE = 0, LDT_BACT_GELU = 1, LDT_BACT_SILU = 2, LD
                      LDT_BACT_RRELU_EVAL = 6, LDT_BACT_HARDSWISH = 7, LDT_BACT_SELU = 8 };
 int ldt_block_activation(uint16_t* x, int64_t ld, int64_t M, int32_t C, int32_t kind, void* stream);
 int ldt_widen_bf16(const uint16_t* src, float* dst, int64_t n, void* stream);
+
+/* ---- the other norms `get_norm` builds (tools/utils.py:168-181; ResidualBlock.norm1 / norm2, FinalLayer.norm: model/layers.py:163-164,235) ----
+ * `norm: group_norm` = nn.GroupNorm(min(C / 4, 16), C, eps = 1e-6) applied to the channels-first (B, C, N) activations: statistics per sample and
+ * group over (C / G channels) x (N tokens), ALWAYS affine (the elementwise_affine flag is ignored upstream).  `norm: ~` = Identity.
+ * (`norm: batch_norm` is undefined upstream: its wrapper feeds (B, N, C) to BatchNorm1d(C) and fails unless tokens == channels.)
+ * ldt_group_stats: stats[b][g] = (mean, rstd) of sample b's `T` token rows x[b*T .. (b+1)*T)[g*C/G .. (g+1)*C/G), biased variance.
+ * ldt_norm_apply:  y[m][c] = bf16( ((x[m][c] - mean) * rstd * w[c] + b[c]) * (1 + scale[s][c]) + shift[s][c] ), (mean, rstd) =
+ *   stats[m / rows_per_stat][c / (C/G)] (stats NULL: 0, 1), w / b NULL: 1 / 0, s = m / rows_per_sample, shift / scale NULL: 0 (layers.py:136-137). */
+int ldt_group_stats(const float* x, int64_t ldx, int32_t B, int32_t T, int32_t C, int32_t G, float eps, float* stats, void* stream);
+int ldt_norm_apply(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t M, int32_t C, const float* stats, int32_t G,
+                   int32_t rows_per_stat, const float* w, const float* b, const float* shift, const float* scale,
+                   int64_t mod_sample_stride, int32_t rows_per_sample, void* stream);
 
 /* LN-folding monitor: *out = max over the M rows of mean^2 / variance, from the row statistics stats[parts][M][2] a
  * ldt_gemm_resid_lnstats launch wrote (K = parts * 256 channels).  The folded projections' rounding error grows as

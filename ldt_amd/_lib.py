@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 20
+ABI_VERSION = 21
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -74,6 +74,8 @@ SIGNATURES = {
     "ldt_sde_score": [_vp, _vp, _i32, C.c_float, C.c_float, C.c_float, _vp, _i32, _i64, _vp],
     "ldt_add_f32": [_vp, _vp, _vp, _i64, _vp],
     "ldt_block_activation": [_vp, _i64, _i64, _i32, _i32, _vp],
+    "ldt_group_stats": [_vp, _i64, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp],
+    "ldt_norm_apply": [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ldt_widen_bf16": [_vp, _vp, _i64, _vp],
     "ldt_fold_mean_ratio": [_vp, _i32, _i64, _i32, _vp, _vp],
     "ldt_fps": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -40,6 +40,8 @@ def pack_block(blk):
         "n1": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm1.affine),
         "n2": tuple(None if p is None else p.detach().float().contiguous() for p in blk.norm2.affine),
         "act": block_act_id(getattr(blk, "act", None)),             # activation behind the norms of the no-condition branch (0 = Identity)
+        "norm": getattr(blk.norm1, "kind", "layer_norm"),            # layer_norm | group_norm | None (tools/utils.py:168-181)
+        "groups": (getattr(blk.norm1, "num_groups", 0), getattr(blk.norm2, "num_groups", 0)),
     }
     if C == Co and C in (64, 128) and blk.dim_kv == C:              # fc_q | fc_kv as one operand for the fused LN + linear kernel
         P["wqkv"] = torch.cat([P["wq"], P["wkv"]], 0).contiguous()
@@ -52,6 +54,20 @@ def pack_block(blk):
         P["wada2"], P["bada2"] = (t.detach().float().contiguous() for t in (blk.adaLN2[1].weight, blk.adaLN2[1].bias))
         P["wsc"], P["bsc"] = _bf(conv_w(blk.shortcut)), blk.shortcut.bias.detach().float().contiguous()
     return P
+
+
+def apply_norm(kind, x, B, N, affine=(None, None), groups=0, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=0):
+    """norm(x) [* w + b] then modulate (layers.py:136-137) -> bf16, for the three norms get_norm builds (tools/utils.py:168-181):
+    layer_norm (the LayerNorm kernel; affine only when the block has no condition), group_norm (statistics per sample and group over
+    C / G channels x the sample's N tokens — the reference applies nn.GroupNorm to the channels-first (B, C, N) tensor — always affine),
+    None (identity).  x: token-major fp32 [B*N, C]."""
+    if kind == "layer_norm":
+        kw = dict(shift=shift, scale=scale, mod_sample_stride=mod_sample_stride, rows_per_sample=rows_per_sample) if shift is not None else {}
+        return ops.layernorm_modulate(x, w=affine[0], b=affine[1], **kw)
+    stats = ops.group_stats(x, B, N, groups) if kind == "group_norm" else None
+    w, b = affine if kind == "group_norm" else (None, None)
+    return ops.norm_apply(x, stats=stats, rows_per_stat=N, w=w, b=b, shift=shift, scale=scale, mod_sample_stride=mod_sample_stride,
+                          rows_per_sample=rows_per_sample if shift is not None else 1)
 
 
 def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x_bf16_out=None, q_pre=None, next_P=None, kv_pre=None):
@@ -85,7 +101,9 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
     # no-condition branch with a block activation (layers.py:224-226, `decoder_act`): act(norm1(x)) feeds fc_q (and fc_kv in self-attention),
     # act(norm2(x)) the MLP — the LayerNorm kernels + one element-wise pass + the GEMMs (the fused LN kernels have no activation slot)
     act = P.get("act", 0) if c is None else 0
-    fused_in = FUSED_ATTN and C in (64, 128) and P["wq"].shape[1] == C and Co % 64 == 0 and x.stride(0) % 4 == 0 and not act
+    kind = P.get("norm", "layer_norm")
+    ln = kind == "layer_norm"                                        # the fused LN kernels are LayerNorm kernels: other norms take the chain below
+    fused_in = FUSED_ATTN and C in (64, 128) and P["wq"].shape[1] == C and Co % 64 == 0 and x.stride(0) % 4 == 0 and not act and ln
     if fused_in:
         # LN1 (+ modulate | affine) + fc_q [+ fc_kv on the same normalised input] in ONE kernel (csrc/fused_mlp.hip):
         # the normalised activations are never written
@@ -102,9 +120,9 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
             kv = kv_pre if kv_pre is not None else ops.gemm_bf16(y_bf16, P["wkv"], P["bkv"], EPI_BF16)
     else:
         if c is not None:
-            h = ops.layernorm_modulate(x, **ln_kw)
+            h = ops.layernorm_modulate(x, **ln_kw) if ln else apply_norm(kind, x, B, Nq, P["n1"], P["groups"][0], **ln_kw)
         else:
-            h = ops.layernorm_modulate(x, w=P["n1"][0], b=P["n1"][1])
+            h = apply_norm(kind, x, B, Nq, P["n1"], P["groups"][0])
             if act:
                 ops.block_activation_(h, act)
         q = ops.gemm_bf16(h, P["wq"], P["bq"], EPI_BF16)
@@ -123,7 +141,7 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
         a = ops.attention_fwd(q, kv[:, :Co], kv[:, Co:], B, H, Nq, Nk, Co // H)     # [B,H,Nq,Dh] == (B*Nq, Co) raw view
         ops.gemm_bf16(a.view(B * Nq, Co), P["wo"], P["bo"], EPI_RESID_F32, out=x, resid=x, gate=g1,
                       gate_sample_stride=s2 if g1 is not None else 0, rows_per_sample=rps)
-    if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0 and not act:
+    if FUSED_MLP and Co in (64, 128) and P["wup"].shape == (4 * Co, Co) and x.stride(0) % 4 == 0 and not act and ln:
         # LN2 + MLP + gated residual in ONE pass over x (csrc/fused_mlp.hip) — the Compressor's d = 128 blocks
         nxt = None
         if next_P is not None and FUSED_ATTN and next_P["C"] == next_P["Co"] == Co and tuple(next_P["wq"].shape) == (Co, Co) \
@@ -139,9 +157,9 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
             return (x, r[1]) if nxt is not None else (x, None)
         return x
     if c is not None:
-        h2 = ops.layernorm_modulate(x, shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
+        h2 = apply_norm(kind, x, B, Nq, P["n2"], P["groups"][1], shift=sh2, scale=sc2, mod_sample_stride=s2, rows_per_sample=rps)
     else:
-        h2 = ops.layernorm_modulate(x, w=P["n2"][0], b=P["n2"][1])
+        h2 = apply_norm(kind, x, B, Nq, P["n2"], P["groups"][1])
         if act:
             ops.block_activation_(h2, act)
     u = ops.gemm_bf16(h2, P["wup"], P["bup"], EPI_GELU_BF16)
@@ -155,7 +173,8 @@ def residual_block(P, x, B, Nq, y_bf16=None, Nk=None, c=None, per_token=False, x
 def pack_final(fl):
     lin = fl.adaLN[1]
     return {"C": fl.ln.in_channels, "w": _bf(conv_w(fl.ln)), "b": fl.ln.bias.detach().float().contiguous(),
-            "n_out": fl.ln.out_channels,
+            "n_out": fl.ln.out_channels, "norm": getattr(fl.norm, "kind", "layer_norm"), "groups": getattr(fl.norm, "num_groups", 0),
+            "n": tuple(None if p is None else p.detach().float().contiguous() for p in fl.norm.affine),
             "wada": lin.weight.detach().float().contiguous(), "bada": lin.bias.detach().float().contiguous()}
 
 
@@ -164,5 +183,6 @@ def final_layer(P, x, B, N, c, out_dtype=torch.float32, per_token=False):
     from ._lib import EPI_F32
     C = P["C"]
     mod = ops.sgemm(c, P["wada"], P["bada"], act_in=ACT_SILU)                      # [B, 2C] shift | scale
-    h = ops.layernorm_modulate(x, shift=mod[:, :C], scale=mod[:, C:], mod_sample_stride=2 * C, rows_per_sample=1 if per_token else N)
+    h = apply_norm(P.get("norm", "layer_norm"), x, B, N, P.get("n", (None, None)), P.get("groups", 0), shift=mod[:, :C], scale=mod[:, C:],
+                   mod_sample_stride=2 * C, rows_per_sample=1 if per_token else N)
     return ops.gemm_bf16(h, P["w"], P["b"], EPI_F32 if out_dtype == torch.float32 else EPI_BF16, n=P["n_out"])

@@ -319,3 +319,76 @@ extern "C" int ldt_fold_mean_ratio(const float* stats, int32_t parts, int64_t M,
     hipLaunchKernelGGL(fold_mean_ratio_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), stats, parts, (long)M, K, out);
     return ldt_check_launch("fold_mean_ratio");
 }
+
+
+// ------------------------------------------------------------------------------------------------- group norm / identity norm
+// tools/utils.py:168-181 get_norm: `group_norm` -> nn.GroupNorm(min(C/4, 16), C, eps=1e-6) on the channels-first activations (statistics per
+// sample and group over C/G channels x all tokens), `None` -> Identity.  Rows are token-major here: x[b*T + t][c].
+__global__ void group_stats_kernel(const float* __restrict__ x, long ldx, int T, int C, int G, float eps, float* __restrict__ stats) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cg = C / G;
+    const float* xb = x + (long)b * T * ldx + g * cg;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < T * cg; i += blockDim.x) {
+        const float v = xb[(long)(i / cg) * ldx + i % cg];
+        s1 += v; s2 += (double)v * v;
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)T * cg, mean = r1[0] / n;
+        double var = r2[0] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stats[(long)blockIdx.x * 2] = (float)mean;
+        stats[(long)blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+extern "C" int ldt_group_stats(const float* x, int64_t ldx, int32_t B, int32_t T, int32_t C, int32_t G, float eps, float* stats, void* stream) {
+    LDT_REQUIRE(x && stats && B > 0 && T > 0 && C > 0 && G > 0 && C % G == 0 && ldx >= C, LDT_EARG, "group_stats: bad argument (B=%d T=%d C=%d G=%d)", B, T, C, G);
+    hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, T, C, G, eps, stats);
+    return ldt_check_launch("group_stats");
+}
+
+__global__ void norm_apply_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long M, int C, const float* __restrict__ stats,
+                                  int G, int rows_per_stat, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ shift,
+                                  const float* __restrict__ scale, long mod_sample_stride, int rows_per_sample) {
+    const long n4 = M * (C / 4);
+    const int cg = C / (G > 0 ? G : 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ldx + c);
+        const long moff = (m / rows_per_sample) * mod_sample_stride + c;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mean = 0.f, rstd = 1.f;
+            if (stats) {
+                const float* st = stats + ((m / rows_per_stat) * G + (c + j) / cg) * 2;
+                mean = st[0]; rstd = st[1];
+            }
+            float h = (v[j] - mean) * rstd;
+            if (w) h = h * w[c + j] + b[c + j];
+            if (scale) h = h * (1.0f + scale[moff + j]) + shift[moff + j];
+            o[j] = (bf16_t)h;
+        }
+        *reinterpret_cast<bf16x4*>(y + m * ldy + c) = o;
+    }
+}
+extern "C" int ldt_norm_apply(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int64_t M, int32_t C, const float* stats, int32_t G,
+                              int32_t rows_per_stat, const float* w, const float* b, const float* shift, const float* scale,
+                              int64_t mod_sample_stride, int32_t rows_per_sample, void* stream) {
+    LDT_REQUIRE(x && y && M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0, LDT_EARG, "norm_apply: bad argument (M=%ld C=%d)", (long)M, C);
+    LDT_REQUIRE(ldt_aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0, LDT_EALIGN, "norm_apply: x must be 16-byte, y 8-byte aligned");
+    LDT_REQUIRE(!stats || (G > 0 && C % G == 0 && rows_per_stat > 0), LDT_EARG, "norm_apply: statistics need G | C and rows_per_stat > 0");
+    LDT_REQUIRE(!w == !b && !shift == !scale && rows_per_sample > 0, LDT_EARG, "norm_apply: w / b and shift / scale go in pairs; rows_per_sample > 0");
+    long blocks = (M * (C / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, reinterpret_cast<bf16_t*>(y), (long)ldy,
+                       (long)M, C, stats, stats ? G : 1, stats ? rows_per_stat : 1, w, b, shift, scale, (long)mod_sample_stride, rows_per_sample);
+    return ldt_check_launch("norm_apply");
+}

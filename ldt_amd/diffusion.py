@@ -570,6 +570,6 @@ def _fused_model(score_fn):
     from .score import Score
     owner = getattr(score_fn, "__self__", None)
     model = getattr(owner, "model", None)
-    if isinstance(model, Score) and not model.unet and _is_stock_score_fn(score_fn):
-        return model                                            # (the U-Net variant is driven by the generic loop)
+    if isinstance(model, Score) and not model.host_blocks and _is_stock_score_fn(score_fn):
+        return model                                            # (the U-Net / non-LayerNorm variants are driven by the generic loop)
     return None

@@ -18,6 +18,7 @@ class _Holder(nn.Module):
 
 class LayerNormC(_Holder):
     """tools/utils.py:127-133 — keys `<name>.norm.{weight,bias}` when affine."""
+    kind = "layer_norm"
 
     def __init__(self, channels, elementwise_affine):
         super().__init__()
@@ -28,11 +29,47 @@ class LayerNormC(_Holder):
         return (self.norm.weight, self.norm.bias) if self.norm.elementwise_affine else (None, None)
 
 
+class IdentityNorm(_Holder):
+    """`norm: ~` -> nn.Identity (tools/utils.py:169-170): no parameters."""
+    kind = None
+    affine = (None, None)
+
+
+class GroupNormC(_Holder):
+    """`norm: group_norm` -> nn.GroupNorm(min(C // 4, groups), C, eps=1e-6) returned AS IS by get_norm (tools/utils.py:177-179): the keys are
+    `<name>.weight` / `<name>.bias` (no `.norm.` infix), the affine is always there (elementwise_affine is ignored upstream; ones / zeros at
+    construction: no generator draw), and it is applied to the channels-first (B, C, N) activations: statistics per sample and group over
+    C / G channels x all tokens.  Parameter holder only (ldt_group_stats / ldt_norm_apply do the arithmetic)."""
+    kind = "group_norm"
+
+    def __init__(self, channels, groups=16):
+        super().__init__()
+        self.num_groups = min(channels // 4, groups)
+        self.num_channels = channels
+        self.eps = 1e-6
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    @property
+    def affine(self):
+        return (self.weight, self.bias)
+
+
 def make_norm(channels, kind, elementwise_affine):
-    """tools/utils.py:168-181 get_norm — only layer_norm is on the shipped path."""
-    if kind is None or str(kind).lower() != "layer_norm":
-        raise NotImplementedError("norm=%r: only 'layer_norm' is built (shipped configs)" % (kind,))
-    return LayerNormC(channels, elementwise_affine)
+    """tools/utils.py:168-181 get_norm: layer_norm (every shipped config), group_norm, None.  `batch_norm` is refused with the reason:
+    upstream's BatchNorm1d wrapper (tools/utils.py:136-142) transposes the (B, C, N) activations to (B, N, C) before nn.BatchNorm1d(C), which
+    then normalises over the TOKEN axis and fails with "running_mean should contain N elements not C" unless tokens == channels."""
+    if kind is None:
+        return IdentityNorm()
+    k = str(kind).lower()
+    if k == "layer_norm":
+        return LayerNormC(channels, elementwise_affine)
+    if k == "group_norm":
+        return GroupNormC(channels, 16)
+    if k == "batch_norm":
+        raise NotImplementedError("norm='batch_norm': undefined upstream — its wrapper feeds (B, tokens, channels) to BatchNorm1d(channels), "
+                                  "which raises unless tokens == channels (tools/utils.py:136-142)")
+    raise TypeError("norm not support")                              # tools/utils.py:181
 
 
 class TimeEmbedding(_Holder):

@@ -226,6 +226,28 @@ def add_f32(a, b, out=None):
     return out
 
 
+def group_stats(x, B, T, groups, eps=1e-6):
+    """(mean, rstd) per (sample, group) of token-major fp32 rows x [B*T, C]: nn.GroupNorm's statistics on the reference's channels-first
+    (B, C, N) tensor (tools/utils.py:177-179) -> fp32 [B, groups, 2]."""
+    _need(x, torch.float32, "x"); _rowmajor(x, "x")
+    C = x.shape[1]
+    out = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    check(lib().ldt_group_stats(_p(x), x.stride(0), B, T, C, groups, float(eps), _p(out), stream_ptr()), "ldt_group_stats")
+    return out
+
+
+def norm_apply(x, stats=None, rows_per_stat=1, w=None, b=None, shift=None, scale=None, mod_sample_stride=0, rows_per_sample=1, out=None):
+    """bf16 [M, C] = ((x - mean) rstd w + b)(1 + scale) + shift with (mean, rstd) from `stats` [S, G, 2] (None: identity norm)."""
+    _need(x, torch.float32, "x"); _rowmajor(x, "x")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+    G = 0 if stats is None else stats.shape[1]
+    check(lib().ldt_norm_apply(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _p(stats), G, rows_per_stat, _p(w), _p(b), _p(shift), _p(scale),
+                               mod_sample_stride, rows_per_sample, stream_ptr()), "ldt_norm_apply")
+    return out
+
+
 def block_activation_(x, kind):
     """x (bf16 [M, C], row-major view) = act(x) in place; kind = _lib.block_act_id(name) (> 0)."""
     _need(x, torch.bfloat16, "x")

@@ -41,6 +41,9 @@ class Score(nn.Module):
         self.num_blocks = cfg.num_blocks
         self.unet = cfg.unet
         self.AdaLN = cfg.AdaLN
+        # norm other than layer_norm (tools/utils.py:168-181: group_norm, None): the blocks run host-driven over the HIP kernels like the
+        # U-Net variant (the fused C++ forward and its LN folding are LayerNorm code); `batch_norm` is refused by make_norm with the reason
+        self.host_blocks = bool(self.unet) or not (isinstance(self.norm, str) and self.norm.lower() == "layer_norm")
         if self.condition:
             from .condition import ConditionNet                     # built first, as upstream (score.py:64-65)
             self.c_net = ConditionNet(self.hidden_size, self.t_dim, patch_size=self.z_scale)
@@ -101,6 +104,14 @@ class Score(nn.Module):
                      "b_in": self.ln_in.bias.detach().float().contiguous(),
                      "up": [pack_block(b) for b in self.Transformer_Up], "mid": pack_block(self.Transformer_Mid),
                      "down": [pack_block(b) for b in self.Transformer_Down], "final": pack_final(self.ln_out)}
+            self._pack, self._pack_key = P, key
+            return P
+        if self.host_blocks:
+            from .blocks import pack_block, pack_final
+            with torch.no_grad():
+                P = {"w_in": ops.cast_pad_bf16(conv_w(self.ln_in).float().contiguous(), ops.pad64(self.z_dim)),
+                     "b_in": self.ln_in.bias.detach().float().contiguous(),
+                     "blocks": [pack_block(b) for b in self.Transformer], "final": pack_final(self.ln_out)}
             self._pack, self._pack_key = P, key
             return P
         with torch.no_grad():
@@ -287,7 +298,7 @@ class Score(nn.Module):
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
         F = self.Transformer[0].mlp.out.in_channels if not self.unet else 0
-        if (self._fold_disabled and mode != 2) or mode == 0 or self.unet:
+        if (self._fold_disabled and mode != 2) or mode == 0 or self.host_blocks:
             return False
         route = int(lib().ldt_score_lnfold_route(M, D, F, gemm_wgs))
         if route == 2:
@@ -374,6 +385,8 @@ class Score(nn.Module):
         x = x.contiguous().float()
         if self.unet:
             return self._forward_unet(x, t, label, condition)
+        if self.host_blocks:
+            return self._forward_host_blocks(x, t, label, condition)
         extra, kv, S = self.condition_embedding(label, condition)
         _, mod = self.time_table(t.to(x).float(), extra_c=extra)
         plan = self.plan(B, T, mod, 0, self.n_mod, kv_cond=kv, cond_tokens=S)      # per-sample AdaLN rows
@@ -390,8 +403,8 @@ class Score(nn.Module):
         `ldt_sample_loop`'s step; used by the full-size parity tests and bench.py's per-kernel timing."""
         if not x.is_cuda:
             raise RuntimeError("Score.forward_shared_t: x is on %s; the HIP path has no CPU fallback" % x.device)
-        if self.unet:
-            raise NotImplementedError("forward_shared_t: the U-Net variant is host-driven (forward)")
+        if self.host_blocks:
+            raise NotImplementedError("forward_shared_t: the U-Net / non-LayerNorm variants are host-driven (forward)")
         B, T, z = x.shape
         assert z == self.z_dim
         x = x.contiguous().float()
@@ -420,6 +433,38 @@ class Score(nn.Module):
         check(lib().ldt_score_forward(ctypes.byref(plan), x.data_ptr(), out.data_ptr(), step.data_ptr(), ops.stream_ptr()),
               "ldt_score_forward")
         return out
+
+    def _forward_host_blocks(self, x, t, label, condition):
+        """The plain block stack with `norm` other than layer_norm (score.py:117-151 with get_norm's group_norm / None, tools/utils.py:168-181):
+        host-driven, every block the kernel chain of ldt_amd/blocks.py (norm kernel -> GEMMs -> attention -> GEMMs); cross-attention to the
+        point condition on the even blocks (:148-149) with K / V from the RAW condition rows."""
+        from ._lib import EPI_F32
+        from .blocks import final_layer, residual_block
+        if isinstance(condition, dict):
+            if not hasattr(self, "c_net"):
+                raise ValueError("a raw condition dict needs cfg.score.condition=True (ConditionNet, score.py:64-65)")
+            condition = self.c_net(condition)
+        pts_cond, img_cond = (None, 0.) if condition is None else condition
+        B, T, _ = x.shape
+        P = self.packed()
+        c = self.time_embedding(t.to(x).float())
+        if label is not None:
+            c = ops.add_f32(c, self.label_embedding(label))
+        elif torch.is_tensor(img_cond):
+            c = ops.add_f32(c, img_cond.to(x).expand_as(c).contiguous())
+        y, S = None, None
+        if torch.is_tensor(pts_cond):                                # (B, hidden, S) channels-first -> token-major raw rows, bf16
+            S = pts_cond.shape[2]
+            yt = pts_cond.to(self._device(), torch.float32).transpose(1, 2).contiguous().view(B * S, self.hidden_size)
+            y = ops.cast_pad_bf16(yt, self.hidden_size)
+        xin = ops.cast_pad_bf16(x.view(B * T, self.z_dim), ops.pad64(self.z_dim))
+        h = ops.gemm_bf16(xin, P["w_in"], P["b_in"], EPI_F32)                       # ln_in
+        for l, Pb in enumerate(P["blocks"]):
+            if y is not None and l % 2 == 0:
+                residual_block(Pb, h, B, T, y_bf16=y, Nk=S, c=c)
+            else:
+                residual_block(Pb, h, B, T, c=c)
+        return final_layer(P["final"], h, B, T, c).view(B, T, self.z_dim)
 
     def _forward_unet(self, x, t, label, condition):
         """`unet: True` variant (score.py:138-146): num_blocks//2 up blocks whose outputs are kept, a mid block, then

@@ -44,6 +44,22 @@ def layer_norm(x, weight=None, bias=None):
     return F.layer_norm(x, (x.shape[-1],), weight, bias, 1e-6)
 
 
+def apply_norm(sd, prefix, x, kind="layer_norm", affine=False):
+    """tools/utils.py:168-181 get_norm applied the way the blocks apply it (model/layers.py:163-164,218-219,224-226,235,244) on token-major
+    x [B, N, C]: `layer_norm` (keys <prefix>.norm.{weight,bias} only when `affine`: blocks / final layers WITHOUT a condition),
+    `group_norm` (nn.GroupNorm(min(C // 4, 16), C, eps=1e-6) on the channels-first (B, C, N) tensor, keys <prefix>.{weight,bias}, always affine),
+    None (Identity).  (`batch_norm` is undefined upstream: its wrapper normalises the token axis of a (B, N, C) tensor with C running statistics.)"""
+    if kind is None:
+        return x
+    k = str(kind).lower()
+    if k == "layer_norm":
+        return layer_norm(x, sd.get(prefix + ".norm.weight") if affine else None, sd.get(prefix + ".norm.bias") if affine else None)
+    if k == "group_norm":
+        C = x.shape[-1]
+        return F.group_norm(x.transpose(1, 2), min(C // 4, 16), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-6).transpose(1, 2)
+    raise NotImplementedError("norm %r" % (kind,))
+
+
 def modulate(x, shift, scale):
     """model/layers.py:136-137 (shift/scale broadcast over tokens)."""
     return x * (1 + scale) + shift
@@ -110,7 +126,7 @@ def block_act(name):
     return table.get(n, F.relu)
 
 
-def residual_block(sd, prefix, x, y, c, num_heads, act=None):
+def residual_block(sd, prefix, x, y, c, num_heads, act=None, norm="layer_norm"):
     """model/layers.py:202-229.
 
     c is not None  -> AdaLN branch (:212-219), LayerNorm without affine.
@@ -123,31 +139,31 @@ def residual_block(sd, prefix, x, y, c, num_heads, act=None):
     if c is not None and prefix + ".shortcut.weight" in sd:
         sh1, sc1 = linear(sd, prefix + ".adaLN1.1", F.silu(c))[:, None, :].chunk(2, dim=-1)
         g1, sh2, sc2, g2 = linear(sd, prefix + ".adaLN2.1", F.silu(c))[:, None, :].chunk(4, dim=-1)
-        h = modulate(layer_norm(x), sh1, sc1)
+        h = modulate(apply_norm(sd, prefix + ".norm1", x, norm), sh1, sc1)
         x = linear(sd, prefix + ".shortcut", x) + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
-        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
+        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(apply_norm(sd, prefix + ".norm2", x, norm), sh2, sc2))
     elif c is not None:
         m = linear(sd, prefix + ".adaLN.1", F.silu(c))                   # [B,6C], or [B,T,6C] for a per-token condition (:210)
         m = m[:, None, :] if m.dim() == 2 else m
         sh1, sc1, g1, sh2, sc2, g2 = m.chunk(6, dim=-1)
-        h = modulate(layer_norm(x), sh1, sc1)
+        h = modulate(apply_norm(sd, prefix + ".norm1", x, norm), sh1, sc1)
         x = x + g1 * attention(sd, prefix, h, h if y is None else y, num_heads)
-        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(layer_norm(x), sh2, sc2))
+        x = x + g2 * mlp(sd, prefix + ".mlp", modulate(apply_norm(sd, prefix + ".norm2", x, norm), sh2, sc2))
     else:                                # (a block BUILT with a condition but called without one has no affine: :172-173)
         fa = block_act(act)              # :224-226: self.act behind both norms (`decoder_act`; Identity in the shipped configs)
-        h = fa(layer_norm(x, sd.get(prefix + ".norm1.norm.weight"), sd.get(prefix + ".norm1.norm.bias")))
+        h = fa(apply_norm(sd, prefix + ".norm1", x, norm, affine=True))
         x = x + attention(sd, prefix, h, h if y is None else y, num_heads)
-        h = fa(layer_norm(x, sd.get(prefix + ".norm2.norm.weight"), sd.get(prefix + ".norm2.norm.bias")))
+        h = fa(apply_norm(sd, prefix + ".norm2", x, norm, affine=True))
         x = x + mlp(sd, prefix + ".mlp", h)
     return x
 
 
-def final_layer(sd, prefix, x, c):
+def final_layer(sd, prefix, x, c, norm="layer_norm"):
     """model/layers.py:232-248: chunk order is (shift, scale)."""
     m = linear(sd, prefix + ".adaLN.1", F.silu(c))
     m = m[:, None, :] if m.dim() == 2 else m
     sh, sc = m.chunk(2, dim=-1)
-    return linear(sd, prefix + ".ln", modulate(layer_norm(x), sh, sc))
+    return linear(sd, prefix + ".ln", modulate(apply_norm(sd, prefix + ".norm", x, norm), sh, sc))
 
 
 # ----------------------------------------------------------------------------- Score
@@ -163,25 +179,26 @@ def score_forward(sd, cfg, x, t, label_emb=None, condition=None, trace=None):
     t_emb = time_embedding(sd, "TimeEmbedding", t, cfg.t_dim // 4)
     c = t_emb + label_emb if label_emb is not None else t_emb + img_cond
     h = linear(sd, "ln_in", x)
+    nk = getattr(cfg, "norm", "layer_norm")                          # score.py:58 -> every block's and the final layer's get_norm
     if trace is not None:
         trace.append(("c", c.clone()))
         trace.append(("ln_in", h.clone()))
     if getattr(cfg, "unet", False):
         skips = [h]
         for i in range(cfg.num_blocks // 2):
-            h = residual_block(sd, "Transformer_Up.%d" % i, h, pts_cond, c, cfg.num_heads)      # every layer gets y (:141)
+            h = residual_block(sd, "Transformer_Up.%d" % i, h, pts_cond, c, cfg.num_heads, norm=nk)      # every layer gets y (:141)
             skips.append(h)
-        h = residual_block(sd, "Transformer_Mid", h, pts_cond, c, cfg.num_heads)
+        h = residual_block(sd, "Transformer_Mid", h, pts_cond, c, cfg.num_heads, norm=nk)
         for i in range(cfg.num_blocks // 2):
             h = torch.cat((h, skips.pop()), dim=-1)                                            # channels [x | skip] (:145)
-            h = residual_block(sd, "Transformer_Down.%d" % i, h, pts_cond, c, cfg.num_heads)
-        return final_layer(sd, "ln_out", h, c)
+            h = residual_block(sd, "Transformer_Down.%d" % i, h, pts_cond, c, cfg.num_heads, norm=nk)
+        return final_layer(sd, "ln_out", h, c, norm=nk)
     for i in range(cfg.num_blocks):
         y = pts_cond if (i % 2 == 0) else None
-        h = residual_block(sd, "Transformer.%d" % i, h, y, c, cfg.num_heads)
+        h = residual_block(sd, "Transformer.%d" % i, h, y, c, cfg.num_heads, norm=nk)
         if trace is not None:
             trace.append(("block%d" % i, h.clone()))
-    return final_layer(sd, "ln_out", h, c)
+    return final_layer(sd, "ln_out", h, c, norm=nk)
 
 
 # ----------------------------------------------------------------------------- VPSDE + samplers
@@ -467,10 +484,10 @@ def initial_set(sd, B, num_points=None, keep_mask=None, seed_eps=None):
     return torch.stack([prior[keep_mask[b]] for b in range(B)], 0)
 
 
-def decoder_block(sd, prefix, o, eps_j, num_heads, c=None, act=None):
+def decoder_block(sd, prefix, o, eps_j, num_heads, c=None, act=None, norm="layer_norm"):
     """model/Compressor/Network.py:80-83: o <- att1(o, ln(eps_j), c) (K/V raw; c: label embedding under class_condition)."""
     z = linear(sd, prefix + ".ln", eps_j)
-    return residual_block(sd, prefix + ".att1", o, z, c, num_heads, act=act)
+    return residual_block(sd, prefix + ".att1", o, z, c, num_heads, act=act, norm=norm)
 
 
 def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
@@ -480,7 +497,7 @@ def compressor_decode(sd, cfg, given_eps, keep_mask=None, seed_eps=None):
     for j in range(cfg.n_layers):
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)                 # reversed(self.decoder), :263
         e_j = given_eps[:, :, cfg.z_dim * j: cfg.z_dim * (j + 1)]  # split along channels, :261-262
-        o = decoder_block(sd, blk, o, e_j, cfg.num_heads, act=getattr(cfg, "decoder_act", None))
+        o = decoder_block(sd, blk, o, e_j, cfg.num_heads, act=getattr(cfg, "decoder_act", None), norm=getattr(cfg, "norm", "layer_norm"))
     return linear(sd, "output", o)                                  # postprocess = identity for xyz, :271-275
 
 
@@ -653,6 +670,7 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
     'set' [B,N,3], plus intermediates for parity tests."""
     B, N, _ = pts.shape
     T = cfg.z_scales
+    nk = getattr(cfg, "norm", "layer_norm")                                     # Network.py:114 -> every block's / final layer's get_norm
     if getattr(cfg, "norm_input", False):                                       # :189-190
         pts = (pts - pts.mean(dim=1, keepdim=True)) / pts.std(dim=1, keepdim=True)
     feat = linear(sd, "input", pts)                                             # :192
@@ -674,19 +692,19 @@ def compressor_encode(sd, cfg, pts, post_noise, fps_idx=None, knn_idx=None, keep
     enc_out = []
     for i in range(cfg.n_layers):                                               # :203-205
         for j in range(cfg.encoder_layers):
-            x = residual_block(sd, "encoder.%d.atts.%d" % (i, j), x, x, pos, cfg.num_heads)   # y = raw x (Q2)
-        enc_out.append(final_layer(sd, "encoder.%d.conv_out" % i, x, pos))
+            x = residual_block(sd, "encoder.%d.atts.%d" % (i, j), x, x, pos, cfg.num_heads, norm=nk)   # y = raw x (Q2)
+        enc_out.append(final_layer(sd, "encoder.%d.conv_out" % i, x, pos, norm=nk))
     o = initial_set(sd, B, keep_mask=keep_mask, seed_eps=seed_eps)              # :215
     all_eps, mus, logvars = [], [], []
     for j in range(cfg.n_layers):                                               # :217-225
         blk = "decoder.%d" % (cfg.n_layers - 1 - j)
         xj = enc_out[-j - 1]
-        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, l_emb, cfg.num_heads, act=getattr(cfg, "decoder_act", None))   # :61-74
+        p = residual_block(sd, blk + ".att", xj, o if j != 0 else xj, l_emb, cfg.num_heads, act=getattr(cfg, "decoder_act", None), norm=nk)   # :61-74
         post = linear(sd, blk + ".prior.1", F.silu(p))                          # :56,:72
         mu = post[..., :cfg.z_dim]
         logvar = post[..., cfg.z_dim:].clamp(cfg.min_sigma, 10.)                # :76
         eps = mu + torch.exp(logvar / 2.) * post_noise[j]                       # :26-29
-        o = decoder_block(sd, blk, o, eps, cfg.num_heads, l_emb, act=getattr(cfg, "decoder_act", None))   # :225
+        o = decoder_block(sd, blk, o, eps, cfg.num_heads, l_emb, act=getattr(cfg, "decoder_act", None), norm=nk)   # :225
         all_eps.append(eps); mus.append(mu); logvars.append(logvar)
     out = linear(sd, "output", o)                                               # :231
     return {"set": out, "all_eps": torch.cat(all_eps, dim=-1), "mu": mus, "logvar": logvars,

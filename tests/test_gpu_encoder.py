@@ -277,6 +277,53 @@ def test_compressor_variants_golden(tiny_cfg):
     assert rel_mse(r["all_eps"].cpu(), a["n_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a["n_set"]) < 1e-3
 
 
+def test_norm_variants_golden(tiny_cfg):
+    """`norm: group_norm` / `norm: ~` (tools/utils.py:168-181: ldt_group_stats + ldt_norm_apply instead of the LayerNorm kernels; the Score runs its
+    blocks host-driven then) vs outputs captured from the reference: Score forward (plain, with point + image condition), a short sampling loop
+    through Trainer.sample vs the oracle, Compressor decode and encode."""
+    import copy
+    import ldt_amd
+    from conftest import load_golden, rel_mse
+    from oracle import ldt_oracle as O
+    a, sds = load_golden("norm_variants")
+    for tag, kind in (("gn", "group_norm"), ("id", None)):
+        cfg = copy.deepcopy(tiny_cfg)
+        cfg.score.norm = kind
+        cfg.compressor.norm = kind
+        cfg.compressor.n_layers, cfg.compressor.encoder_layers = 2, 1
+        score = ldt_amd.Score(cfg.score)
+        score.load_state_dict(sds[tag + "s"], strict=True)
+        score = score.cuda()
+        out = score(a["x"].cuda(), a["t"].cuda())
+        assert rel_mse(out.cpu(), a[tag + "_out"]) < 1e-4, tag
+        cond = (a["pts_cond"].transpose(1, 2).contiguous().cuda(), a["img_cond"].cuda())
+        out = score(a["x"].cuda(), a["t"].cuda(), condition=cond)
+        assert rel_mse(out.cpu(), a[tag + "_out_cond"]) < 1e-4, tag
+        comp = ldt_amd.Compressor(cfg.compressor)
+        comp.load_state_dict(sds[tag + "c"], strict=True)
+        comp = comp.cuda(); comp.init()
+        dec = comp.sample((2, 64), given_eps=a["given_eps"].cuda())
+        assert rel_mse(dec.cpu(), a[tag + "_points"]) < 1e-4, tag
+        r = comp(a["pts"].cuda(), post_noise=list(a[tag + "_post_noise"]))
+        assert rel_mse(r["all_eps"].cpu(), a[tag + "_all_eps"]) < 1e-3 and rel_mse(r["set"].cpu(), a[tag + "_set"]) < 1e-3, tag
+        # the sampling loop (generic, Python-driven: the fused C++ loop is LayerNorm code) on injected noise vs the oracle
+        N = 25                                                                   # (N <= 20 makes beta > 1: the ancestral update is not finite)
+        sde_cfg = copy.deepcopy(cfg.sde); sde_cfg.sample_N = N
+        B, T, z = 2, cfg.score.z_scale, cfg.score.z_dim
+        x0, noises = O.draw_noises(5, B, T, z, N)
+        sde = ldt_amd.DiffusionVPSDE(sde_cfg)
+        tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+        eps = sde.sample_discrete(score_fn=tr.score_fn, num_samples=B, N=N, predictor="ancestral", corrector=None, corrector_steps=1, shape=(T, z),
+                                  time_eps=sde_cfg.sample_time_eps, probability_flow=False, denoise=True, snr=0.01, device="cuda:0",
+                                  x0=x0, noise=torch.stack(noises))
+        osde = O.VPSDE(sde_cfg)
+        cs = copy.deepcopy(cfg.score)
+        fn = O.score_fn_from_model(osde, lambda xx, tt: O.score_forward(sds[tag + "s"], cs, xx, tt))
+        with torch.no_grad():
+            ref = O.sample_discrete(osde, fn, x0, noises, N)
+        assert bool(torch.isfinite(ref).all()) and rel_mse(eps.cpu(), ref) < 1e-4, tag
+
+
 def test_compressor_options_golden(tiny_cfg):
     """norm_input + pre_group and the mixture InitialSet (max_outputs None) vs outputs captured from the reference."""
     import copy

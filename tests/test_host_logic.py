@@ -78,6 +78,23 @@ def test_score_block_variant_guards(tiny_cfg):
     assert comp.decoder[0].att1.act == "relu" and block_act_id("relu") == 3 and block_act_id("no-such-name") == 3 and block_act_id(None) == 0
     cc.ActNorm = None
     assert not any(k.startswith("conv_in.") for k in ldt_amd.Compressor(cc).state_dict())
+    # get_norm's other kinds (tools/utils.py:168-181): group_norm and None construct with the reference's state_dict keys (fixture captured from
+    # the reference: tests/golden/norm_variants.npz); batch_norm is refused with the upstream failure it would run into
+    from conftest import load_golden
+    _, sds = load_golden("norm_variants")
+    for tag, kind in (("gn", "group_norm"), ("id", None)):
+        cs = copy.deepcopy(tiny_cfg.score); cs.norm = kind
+        m = ldt_amd.Score(cs)
+        assert m.host_blocks and sorted(m.state_dict()) == sorted(sds[tag + "s"])
+        ck = copy.deepcopy(tiny_cfg.compressor); ck.norm = kind
+        ck.n_layers, ck.encoder_layers = 2, 1
+        assert sorted(ldt_amd.Compressor(ck).state_dict()) == sorted(sds[tag + "c"])
+    cs.norm = "batch_norm"
+    with pytest.raises(NotImplementedError, match="tokens == channels"):
+        ldt_amd.Score(cs)
+    cs.norm = "no_such_norm"
+    with pytest.raises(TypeError, match="norm not support"):
+        ldt_amd.Score(cs)
 
 
 def _sde_cfg(tiny_cfg, name, a):

@@ -275,6 +275,26 @@ def test_compressor_variants(tiny_cfg):
     assert rel_mse(r["all_eps"], a["n_all_eps"]) < 1e-9 and rel_mse(r["set"], a["n_set"]) < 1e-9
 
 
+def test_norm_variants(tiny_cfg):
+    """`norm: group_norm` and `norm: ~` (tools/utils.py:168-181) for the Score (plain, with point + image condition) and the Compressor (decode,
+    encode) vs outputs captured from the reference (oracle/gen_norm_variants_golden.py); `batch_norm` raised upstream when the fixture was made."""
+    import copy
+    a, sds = load_golden("norm_variants")
+    assert float(a["batch_norm_error"]) == 1.0
+    for tag, kind in (("gn", "group_norm"), ("id", None)):
+        cs = copy.deepcopy(tiny_cfg.score); cs.norm = kind
+        out = O.score_forward(sds[tag + "s"], cs, a["x"], a["t"])
+        assert rel_mse(out, a[tag + "_out"]) < TOL, tag
+        out = O.score_forward(sds[tag + "s"], cs, a["x"], a["t"], condition=(a["pts_cond"], a["img_cond"]))
+        assert rel_mse(out, a[tag + "_out_cond"]) < TOL, tag
+        cc = copy.deepcopy(tiny_cfg.compressor); cc.norm = kind
+        cc.n_layers, cc.encoder_layers = 2, 1
+        assert rel_mse(O.compressor_decode(sds[tag + "c"], cc, a["given_eps"]), a[tag + "_points"]) < TOL, tag
+        r = O.compressor_encode(sds[tag + "c"], cc, a["pts"], list(a[tag + "_post_noise"]))
+        assert rel_mse(r["all_eps"], a[tag + "_all_eps"]) < 1e-9 and rel_mse(r["set"], a[tag + "_set"]) < 1e-9, tag
+    assert rel_mse(a["gn_out"], a["id_out"]) > 1e-3                            # the norm matters
+
+
 def test_encoder(tiny_cfg):
     a, _ = load_golden("compressor_fwd_tiny")
     sd = load_golden("trainer_sample_tiny")[1]["c"]
