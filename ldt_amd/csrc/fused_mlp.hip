@@ -26,6 +26,22 @@
 
 #define LDT_MLP_RT_DEFAULT 2          /* 16-row tiles per wave of ln_mlp_resid_kernel: 2 = 4 waves x 32 rows, 1 = 8 waves x 16 rows */
 
+// tools/dbg build (-DMLP_STAMPS): wall-clock stamps (s_memrealtime, 10 ns) of wave 0 of every workgroup, kept in a VGPR (lane i = stamp i) and
+// stored once at the wave's end -> g_mlp_stamps[workgroup][64]; lane 62 = HW_ID, lane 63 = XCC_ID (tools/dbg/mlp_stamps.py)
+#ifdef MLP_STAMPS
+__device__ long long* g_mlp_stamps;
+extern "C" int ldt_dbg_mlp_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_stamps), &p, sizeof(p)); }
+#define MLP_STAMP_DECL() long long _stv = 0
+#define MLP_STAMP(idx) do { const long long _t = __builtin_amdgcn_s_memrealtime(); _stv = (lane == (idx)) ? _t : _stv; } while (0)
+#define MLP_STAMP_FLUSH() do { if (wave == 0 && g_mlp_stamps) { \
+        const long long _h = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)), _x = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); \
+        _stv = lane == 62 ? _h : lane == 63 ? _x : _stv; g_mlp_stamps[(long)blockIdx.x * 64 + lane] = _stv; } } while (0)
+#else
+#define MLP_STAMP_DECL()
+#define MLP_STAMP(idx)
+#define MLP_STAMP_FLUSH()
+#endif
+
 namespace {
 
 template <int C> struct MlpCfg {
@@ -77,57 +93,91 @@ struct LnSrc {
 };
 template <int C, bool LOAD = true, int RT = 2>    // RT = 16-row tiles per wave; LOAD = false: `xv` already holds the rows (the MLP kernel's freshly updated x)
 __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char* Hs, int wave, int lrow, int lq,
-                                                 f32x4 (&xv)[C / 16][RT], bf16x8 (&hf)[C / 32][RT]) {
+                                                 f32x4 (&xv)[C / 16][RT], bf16x8 (&hf)[C / 32][RT], long long* stv = nullptr) {
     using K = MlpCfg<C>;
-    bf16x4 hpk[C / 16][RT];
+    constexpr int NN = C / 16;
+#ifdef MLP_STAMPS
+    const int lane = lq * 16 + lrow;
+    long long _stv = stv ? *stv : 0;
+#define LN_STAMP(idx) MLP_STAMP(idx)
+#else
+#define LN_STAMP(idx)
+#endif
+    // Every request of this phase goes out in ONE flight: the rows of all RT tiles, then the LayerNorm vectors of the lane's channels (they
+    // used to be loaded where they are used, inside the per-channel loops under `if (a.ln_w)`: a load + wait per channel group and tile).
+    // Worth 0.5 % only: in-kernel stamps (tools/dbg/mlp_stamps.py, profiles/r05_fused_mlp_analysis.txt) show this phase's 10.6 us per
+    // workgroup are INSTRUCTION ISSUE beside the co-resident workgroup's chunk loop (4.5 us to get the 32 requests out, by which time
+    // the data has landed; 4-5 us of LayerNorm arithmetic), not memory round trips.
+    long grow[RT], moff[RT];
+    const bool aff = a.ln_w != nullptr, mod = a.shift != nullptr;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        long grow = row0 + rt * 16 + lrow;
-        grow = grow < a.M ? grow : a.M - 1;                            // tail rows: clamp, never stored
+        grow[rt] = row0 + rt * 16 + lrow;
+        grow[rt] = grow[rt] < a.M ? grow[rt] : a.M - 1;                // tail rows: clamp, never stored
+        moff[rt] = !mod ? 0 : a.M < (1L << 31) ? (long)((unsigned)grow[rt] / (unsigned)a.rows_per_sample) * a.mod_sample_stride   // (no 64-bit division routine)
+                                               : (grow[rt] / a.rows_per_sample) * a.mod_sample_stride;
         if (LOAD) {
-            const float* xr = a.x + grow * a.ldx + lq * 4;
+            const float* xr = a.x + grow[rt] * a.ldx + lq * 4;
 #pragma unroll
-            for (int n = 0; n < C / 16; ++n) xv[n][rt] = *reinterpret_cast<const f32x4*>(xr + n * 16);
+            for (int n = 0; n < NN; ++n) xv[n][rt] = *reinterpret_cast<const f32x4*>(xr + n * 16);
         }
+    }
+    LN_STAMP(50);
+    // va | vb: the affine (w, b); without an affine LayerNorm, tile 0's (shift, scale) — which is every tile's when the wave's rows share a sample
+    f32x4 va[NN], vb[NN];
+    if (aff) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) { va[n] = *reinterpret_cast<const f32x4*>(a.ln_w + n * 16 + lq * 4); vb[n] = *reinterpret_cast<const f32x4*>(a.ln_b + n * 16 + lq * 4); }
+    } else if (mod) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) { va[n] = *reinterpret_cast<const f32x4*>(a.shift + moff[0] + n * 16 + lq * 4); vb[n] = *reinterpret_cast<const f32x4*>(a.scale + moff[0] + n * 16 + lq * 4); }
+    }
+    LN_STAMP(51);
+#ifdef MLP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LN_STAMP(52);
+#endif
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
         float s = 0.f;
 #pragma unroll
-        for (int n = 0; n < C / 16; ++n) s += (xv[n][rt][0] + xv[n][rt][1]) + (xv[n][rt][2] + xv[n][rt][3]);
+        for (int n = 0; n < NN; ++n) s += (xv[n][rt][0] + xv[n][rt][1]) + (xv[n][rt][2] + xv[n][rt][3]);
         s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
         const float mean = s / (float)C;
         float q = 0.f;
 #pragma unroll
-        for (int n = 0; n < C / 16; ++n)
+        for (int n = 0; n < NN; ++n)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = xv[n][rt][j] - mean; q += d * d; }
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         const float rstd = rsqrtf(q / (float)C + 1e-6f);
-        const long moff = a.shift ? (grow / a.rows_per_sample) * a.mod_sample_stride : 0;
+        // (shift, scale) of this tile's rows: tile 0's registers when no lane's row left tile 0's sample (the Compressor: rows_per_sample is a
+        // multiple of 32); loaded channel group by channel group otherwise (and behind an affine LayerNorm, which no shipped block combines
+        // with a modulation)
+        const bool mod_regs = mod && !aff && (rt == 0 || !__any(moff[rt] != moff[0]));
 #pragma unroll
-        for (int n = 0; n < C / 16; ++n) {
-            const int col = n * 16 + lq * 4;
+        for (int n = 0; n < NN; ++n) {
             f32x4 h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) h[j] = (xv[n][rt][j] - mean) * rstd;
-            if (a.ln_w) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(a.ln_w + col), b = *reinterpret_cast<const f32x4*>(a.ln_b + col);
+            if (aff) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = h[j] * w[j] + b[j];
+                for (int j = 0; j < 4; ++j) h[j] = h[j] * va[n][j] + vb[n][j];
             }
-            if (a.shift) {
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + moff + col), sc = *reinterpret_cast<const f32x4*>(a.scale + moff + col);
+            if (mod_regs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = h[j] * (1.f + vb[n][j]) + va[n][j];
+            } else if (mod) {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + moff[rt] + n * 16 + lq * 4), sc = *reinterpret_cast<const f32x4*>(a.scale + moff[rt] + n * 16 + lq * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h[j] = h[j] * (1.f + sc[j]) + sh[j];
             }
-            hpk[n][rt] = (bf16x4){(bf16_t)h[0], (bf16_t)h[1], (bf16_t)h[2], (bf16_t)h[3]};
+            const int hr = wave * (16 * RT) + rt * 16 + lrow;           // (rows of the image are wave-private)
+            *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) =
+                (bf16x4){(bf16_t)h[0], (bf16_t)h[1], (bf16_t)h[2], (bf16_t)h[3]};
         }
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int n = 0; n < C / 16; ++n) {
-            const int hr = wave * (16 * RT) + rt * 16 + lrow;
-            *reinterpret_cast<bf16x4*>(Hs + hr * K::ROWB + (((n * 2 + (lq >> 1)) ^ swz<K::CB>(hr)) << 4) + (lq & 1) * 8) = hpk[n][rt];
-        }
+    LN_STAMP(53);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // rows are wave-private: ordering inside the wave suffices
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks)
@@ -136,6 +186,10 @@ __device__ __forceinline__ void ln_rows_to_frags(const LnSrc& a, long row0, char
             const int hr = wave * (16 * RT) + rt * 16 + lrow;
             hf[ks][rt] = *reinterpret_cast<const bf16x8*>(Hs + hr * K::ROWB + (((ks * 4 + lq) ^ swz<K::CB>(hr)) << 4));
         }
+#ifdef MLP_STAMPS
+    if (stv) *stv = _stv;
+#endif
+#undef LN_STAMP
 }
 
 // out[rows][N] (bf16) = h . W^T + bias for the wave's 32 rows held as operand fragments `hf`; W streamed in chunks of 64 output
@@ -213,6 +267,8 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
     const long row0 = (long)blockIdx.x * 128 + wave * (16 * RT);              // this wave's 32 rows
     const int lrow = lane & 15, lq = lane >> 4;
 
+    MLP_STAMP_DECL();
+    MLP_STAMP(0);
     stage_wup<C, NW>(a.w_up, 0, W0, wave, lane);                           // chunk 0 weights fly under the LayerNorm
     stage_wdn<C, NW>(a.w_dn, 0, W0 + K::WUP_BYTES, wave, lane);
 
@@ -222,7 +278,13 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
     bf16x8 hf[C / 32][RT];
     {
         const LnSrc src{a.x, a.ldx, a.M, a.ln_w, a.ln_b, a.shift, a.scale, a.mod_sample_stride, a.rows_per_sample};
+#ifdef MLP_STAMPS
+        MLP_STAMP(49);
+        ln_rows_to_frags<C, true, RT>(src, row0, Hs, wave, lrow, lq, oacc, hf, &_stv);
+#else
         ln_rows_to_frags<C, true, RT>(src, row0, Hs, wave, lrow, lq, oacc, hf);
+#endif
+        MLP_STAMP(1);
 #pragma unroll
         for (int n = 0; n < C / 16; ++n) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_dn + n * 16 + lq * 4);
@@ -241,8 +303,11 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
 #endif
         // chunk ch's weights (issued one chunk ago) have landed for this wave; after the barrier: for every wave, and every
         // wave is past chunk ch-1 (and, at ch = 0, has its h fragments in registers), so the other set may be refilled
+        MLP_STAMP(2 + 4 * ch);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MLP_STAMP(3 + 4 * ch);
         __builtin_amdgcn_s_barrier();
+        MLP_STAMP(4 + 4 * ch);
         char* Wu = (ch & 1) ? Hs : W0;
         char* Wd = Wu + K::WUP_BYTES;
         if (ch + 1 < K::NCH) {
@@ -289,6 +354,7 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // U rows are wave-private: ordering inside the wave suffices
+        MLP_STAMP(5 + 4 * ch);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + lq;
@@ -309,6 +375,7 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
     }
 
     // ---- 3. store: lane holds channels n*16 + lq*4 .. +3 of row rt*16 + lrow ---------------------------------------
+    MLP_STAMP(40);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const long grow = row0 + rt * 16 + lrow;
@@ -341,6 +408,13 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 4 : 2) void ln_mlp_resid_kernel
             }
         }
     }
+
+#ifdef MLP_STAMPS
+    MLP_STAMP(41);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MLP_STAMP(42);
+    MLP_STAMP_FLUSH();
+#endif
 
     // ---- 4. (optional) the NEXT block's LayerNorm + first projection on the rows just produced (model/layers.py:218 / :225 of the
     //         block that follows): its LN(x) . W^T is computed from the accumulators, so that block never reads x for it ----------

@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = re.sub(r"^void ", "", r["Kernel_Name"])
-            name = re.sub(r"\(.*$", "", name).replace("(anonymous namespace)::", "")
+            name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 counters = sorted({c for d in acc.values() for c in d})
 print("%-58s %6s " % ("kernel", "calls") + " ".join("%24s" % c for c in counters) + "  derived")
