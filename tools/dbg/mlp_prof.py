@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ldt_amd import ops
-C, M = 128, int(os.environ.get("ROWS", 1024 * 2048))
+C, M = int(os.environ.get("CH", 128)), int(os.environ.get("ROWS", 1024 * 2048))
 torch.manual_seed(0)
 x = torch.randn(M, C, device="cuda")
 w_up = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).to(torch.bfloat16); w_dn = (torch.randn(C, 4 * C, device="cuda") / (4 * C) ** 0.5).to(torch.bfloat16)
