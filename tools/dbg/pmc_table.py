@@ -20,6 +20,10 @@ for k, d in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE",
         extra.append("mfma_util %.3f" % (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)))
     if "SQ_LDS_BANK_CONFLICT" in avg and avg.get("SQ_LDS_IDX_ACTIVE"):
         extra.append("lds_conflict/active %.3f" % (avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]))
+    if avg.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_ANY" in avg:          # disjoint shares of a wave's cycles (MI355X_MICROARCH.md, SQ counters)
+        wc = avg["SQ_WAVE_CYCLES"]
+        extra.append("wave cycles: issuing %.3f issue-stalled %.3f parked %.3f" % (avg["SQ_ACTIVE_INST_ANY"] / wc, avg.get("SQ_WAIT_INST_ANY", float("nan")) / wc, avg.get("SQ_WAIT_ANY", float("nan")) / wc))
+        if avg.get("SQ_WAVES"): extra.append("kcycles/wave %.1f" % (4e-3 * wc / avg["SQ_WAVES"]))
     if "FETCH_SIZE" in avg: extra.append("fetch %.1f MB" % (avg["FETCH_SIZE"] * 1024 / 1e6))
     if "WRITE_SIZE" in avg: extra.append("write %.1f MB" % (avg["WRITE_SIZE"] * 1024 / 1e6))
     print("%-58s %6d " % (k[:58], n) + " ".join("%24.0f" % avg.get(c, float("nan")) for c in counters) + "  " + "; ".join(extra))
