@@ -511,6 +511,13 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
     # (2048 x d) read + written by each of the block's 7 kernels -> HBM-bound time at 8 TB/s
     unfused_bytes = L * 7 * 2 * 2048 * d * 4.0
     unfused_clouds_s = PEAK_HBM_GBS * 1e9 / unfused_bytes
+    # The floors of the FUSED decode path itself, per cloud (a fused path is not graded against an unfused bound).  Per level
+    # two launches touch the (2048 x d) set: attention + fc_o + residual (q bf16 in, x fp32 in + out) and LN + MLP + residual + the next
+    # level's q (x fp32 in + out, q bf16 out) = 20 B per row and channel; the matrix pipe: dec_flops at the dense bf16 peak; VALU issue on 1024
+    # SIMDs at 2.4 GHz: 16 cycles per 64 attention scores (hb() below) + 1048 cycles per 2048 hidden activations of the MLP (the kernel's
+    # measured mix: 230 VALU at 4 cycles + 32 v_exp at 8 per wave and 32 x 64 chunk, profiles/r05_fused_mlp_analysis.txt).
+    fused_fl = {"hbm_us": L * 2048 * d * 20.0 / (PEAK_HBM_GBS * 1e9) * 1e6, "mfma_us": dec_flops / (PEAK_BF16_TFLOPS * 1e12) * 1e6,
+                "valu_issue_us": L * (cc.num_heads * 2048.0 * T / 64.0 * 16.0 + 2048.0 * 4 * d / 2048.0 * 1048.0) / 1024.0 / 2.4e9 * 1e6}
     # cross-attention kernel alone (d = 128, 4 heads x 32), 128 clouds per launch
     Bm, H, dh = 128, cc.num_heads, d // cc.num_heads
 
@@ -577,9 +584,15 @@ def extra_c4(tokens=256, batch=1024, chunk=1024):
                        "decode_clouds_per_s_min_max": [round(batch / st_dec["max_s"], 1), round(batch / st_dec["min_s"], 1)]},
             "decode_roofline": {"bound": "mfma", "achieved": round(dec_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(dec_tf / PEAK_BF16_TFLOPS, 4), "flops_per_cloud": dec_flops},
-            "decode_unfused_lower_bound": {"what": "7 kernels per block each reading + writing the fp32 (2048 x %d) set at 8 TB/s" % d,
-                                           "clouds_per_s": round(unfused_clouds_s, 1), "bytes_per_cloud": unfused_bytes,
-                                           "measured_over_bound": round(batch / t_dec / unfused_clouds_s, 3)},
+            "decode_fused_floors": {"what": "floors of the fused decode path per cloud (HBM: 20 B per row, channel and level at 8 TB/s; matrix pipe; VALU issue)",
+                                    "floors_us_per_cloud": {k: round(v, 2) for k, v in fused_fl.items()}, "bound": max(fused_fl, key=fused_fl.get)[:-3],
+                                    "measured_us_per_cloud": round(t_dec / batch * 1e6, 2),
+                                    "frac": round(max(fused_fl.values()) / (t_dec / batch * 1e6), 4),
+                                    "no_overlap_sum_us": round(sum(fused_fl.values()), 2)},
+            "decode_unfused_reference": {"what": "NOT a bound of this path: what an unfused chain (7 kernels per block each reading + writing the fp32 "
+                                                 "(2048 x %d) set) could reach at 8 TB/s" % d,
+                                         "clouds_per_s": round(unfused_clouds_s, 1), "bytes_per_cloud": unfused_bytes,
+                                         "measured_over_it": round(batch / t_dec / unfused_clouds_s, 3)},
             "cross_attn_q2048_kvT": hb(b1, t1, 2048, T), "cross_attn_qT_kv2048": hb((2 * Bm * T * d + 2 * Bm * 2048 * d) * 2.0, t2, T, 2048),
             "parity": par,
             "cpu_baseline": {"encode_clouds_per_s": round(nb / t_ce, 3), "decode_clouds_per_s": round(nb / t_cd, 3), "cores": host_cores(),
