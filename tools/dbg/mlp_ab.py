@@ -2,7 +2,7 @@
 """A/B of the Compressor's fused MLP kernel (`ln_mlp_resid_kernel`) between builds of libldt_hip.so, alternating child processes on one box:
 the kernel alone at ROWS rows (default 2 M = a decoder level of 1024 clouds; plain and AdaLN-gated), a CRC of its output (same arithmetic per
 row => the builds must agree bit for bit), and Compressor encode / decode of 1024 clouds.
-usage: mlp_ab.py libA.so libB.so [...] [rounds]      ("product" = the in-tree library)"""
+usage: mlp_ab.py libA.so libB.so [...] [rounds]      ("product" = the in-tree library; "lib@VAR=VAL" sets an environment switch for that leg)"""
 import os, subprocess, sys
 libs = [a for a in sys.argv[1:] if not a.isdigit()]
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 2
@@ -52,8 +52,11 @@ print(" | ".join(out))
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ)
-        if l != "product":
-            env["LDT_HIP_LIB"] = l
+        lib, _, kv = l.partition("@")                     # "lib.so@VAR=VAL": the library with an environment switch set
+        if kv:
+            env[kv.split("=")[0]] = kv.split("=")[1]
+        if lib != "product":
+            env["LDT_HIP_LIB"] = lib
         out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True)
         if out.returncode != 0:
             print(out.stdout[-500:], out.stderr[-2000:]); sys.exit(1)
