@@ -265,6 +265,10 @@ def roofline_pass(trainer, cfg, B, reps=3):
             r["fused"] = "QKV projection + self-attention of the block in one launch: flops_per_launch = projection + attention"
         roofs[name] = r
     dom = max((n for n in roofs if n.startswith("gemm_")), key=lambda n: kernels[n]["ms_per_forward"])
+    # mlp.out and MLP-up + GELU take 3.0-3.1 ms of a forward each and swap places from box to box: within 2 % of the maximum the line names
+    # mlp.out (the class DESIGN.md and the committed profiles call dominant), so that successive bench lines price the same kernel
+    if "gemm_dn" in roofs and kernels["gemm_dn"]["ms_per_forward"] >= 0.98 * kernels[dom]["ms_per_forward"]:
+        dom = "gemm_dn"
     return roofs[dom], roofs, kernels
 
 
