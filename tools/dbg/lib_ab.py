@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Whole-loop A/B of two builds of libldt_hip.so on one box: runs `sample()` (N SDE steps, B=64, T=256) in a child
-process per library, alternating, and prints ms per step (AB_TOKENS / AB_BATCH in the environment pick another workload).   usage: lib_ab.py N libA.so libB.so [rounds]"""
+process per library, alternating, and prints ms per step (AB_TOKENS / AB_BATCH in the environment pick another workload).   usage: lib_ab.py N libA.so libB.so [libC.so ...] [rounds]"""
 import os, subprocess, sys
-N, libs = sys.argv[1], sys.argv[2:4]
-rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+N = sys.argv[1]
+libs = [a for a in sys.argv[2:] if not a.isdigit()]                 # two or more builds ("product" = the in-tree one)
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() and len(sys.argv) > 3 else 2
 child = r'''
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
