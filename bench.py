@@ -93,6 +93,9 @@ def parse(argv=None):
     return args
 
 
+RENDEZVOUS_RETRY_WINDOW_S = 120.0      # self_launch repeats a launch only when the child failed this early on the store's bind
+
+
 def needs_self_launch(args, environ):
     """True when this process must start the ranks itself: more than one GPU asked for (or --force-launch) and no launcher
     (torch.distributed.run sets RANK) started us."""
@@ -121,21 +124,25 @@ def self_launch(args, argv, attempts=3):
             port = s.getsockname()[1]
         cmd = launcher_argv(argv, args.gpus, port)
         log("no launcher in the environment: starting %d rank(s): %s" % (args.gpus, " ".join(cmd)))
-        child = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        t_start = time.time()
+        child = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE)     # bytes: an undecodable byte must not end the relay
         in_use = []
 
         def relay():
-            for ln in child.stderr:
+            for raw in child.stderr:
+                ln = raw.decode("utf-8", errors="replace")
                 sys.stderr.write(ln)
-                if "EADDRINUSE" in ln or "ddress already in use" in ln:
+                # only the rendezvous store's own bind failure counts (c10d TCPStore / the elastic agent), not any later socket error
+                if ("EADDRINUSE" in ln or "ddress already in use" in ln) and any(k in ln for k in ("TCPStore", "c10d", "rendezvous", "store", "%d" % port)):
                     in_use.append(ln)
             sys.stderr.flush()
 
         th = threading.Thread(target=relay, daemon=True)
         th.start()
         rc = child.wait()
-        th.join(timeout=10)
-        if rc == 0 or not in_use:
+        th.join()                                                         # the pipe is at EOF once the child is gone
+        early = time.time() - t_start < RENDEZVOUS_RETRY_WINDOW_S         # a bind failure ends the child before any rank has run
+        if rc == 0 or not in_use or not early:
             return rc
         log("rendezvous port %d was taken before the child bound it (attempt %d of %d)" % (port, attempt + 1, attempts))
     return rc

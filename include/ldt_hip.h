@@ -364,7 +364,7 @@ int ldt_score_forward_profile(const ldt_score_plan* plan, const float* x, float*
 typedef struct ldt_cond_args {
     const float* temb;    /* [n_steps][t_dim]  TimeEmbedding(t_i) for every step (host builds it once per call) */
     const float* extra;   /* [batch][t_dim]    label / image-condition embedding, or NULL */
-    const float* w_ada;   /* [n_mod][t_dim]    every block's adaLN.1 weight stacked in plan order (+ FinalLayer's) */
+    const float* w_ada;   /* [n_mod][t_dim]    every block's adaLN.1 weight stacked in plan order (+ FinalLayer's); may be NULL when w_ada_bf16 is given */
     const float* b_ada;   /* [n_mod] */
     float* c_buf;         /* [batch][t_dim]    scratch */
     float* mod_buf;       /* [batch][n_mod]    scratch; plan->mod must point here with mod_sample_stride = n_mod */
@@ -372,7 +372,8 @@ typedef struct ldt_cond_args {
     /* optional (both or neither): the stacked adaLN weights as a bf16 panel [n_mod][t_dim] and a bf16 scratch [batch][t_dim].  When
      * given, the per-step rows are one bf16 MFMA GEMM (fp32 accumulation and bias) that streams 2 bytes per weight instead of 4 —
      * the fp32 form is HBM-bound on its 4 n_mod t_dim bytes per step (BASELINE configs[4]: 604 MB, 9 % of a step).  Rows then carry
-     * bf16 operand rounding (relative MSE ~5e-6), like every token GEMM of the model. */
+     * bf16 operand rounding (relative MSE ~5e-6), like every token GEMM of the model.  The MFMA GEMM needs t_dim % 64 == 0: with another
+     * width the loop uses the fp32 w_ada rows if they were given too, and returns LDT_ESHAPE otherwise. */
     const void* w_ada_bf16;
     void* c_buf_bf16;
 } ldt_cond_args;
@@ -394,6 +395,9 @@ int ldt_dbg_gemm_group_m(int32_t rows_per_group);
 /* tools/dbg/epi_ablate.py: skip parts of the residual epilogue (bit 1 residual read, 2 fp32 store, 4 bf16 x(1+scale) store,
  * 8 row statistics) to attribute its time; -1 restores the product behaviour.  Process-wide; not used by the product path. */
 int ldt_dbg_gemm_epi(int32_t bits);
+/* tools/dbg + tests: 1 = every 256-tile GEMM launch without a fragment-order weight copy packs one on the fly (cached by pointer and
+ * shape, never invalidated) and runs the W-from-registers form; 0 = that form off; -1 restores the product behaviour.  Process-wide. */
+int ldt_dbg_gemm_wreg(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "ldt_score_forward_profile": [C.POINTER(ScorePlan), _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp],
     "ldt_dbg_gemm_group_m": [_i32],
     "ldt_dbg_gemm_epi": [_i32],
+    "ldt_dbg_gemm_wreg": [_i32],
     "ldt_sample_loop": [C.POINTER(ScorePlan), _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i64, _u64, _vp, _i32, C.POINTER(CondArgs), _vp, _i32, _vp],
 }
 

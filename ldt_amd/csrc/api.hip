@@ -432,7 +432,7 @@ static int enqueue_step(const ldt_score_plan* p, float* x, float* x_mean, float*
                         const ldt_cond_args* cond, float* x_traj, hipStream_t s) {
     if (cond) {                                                 // per-sample AdaLN rows of this step
         TRY(ldt_cond_rows_launch(cond->temb, cond->extra, cond->c_buf, cond->c_buf_bf16, step_counter, p->batch, cond->t_dim, 1, s));   // c_buf = silu(c)
-        if (cond->w_ada_bf16) {                                 // bf16 weight panel: half the bytes of the HBM-bound row GEMM (fp32 accumulation + bias)
+        if (cond->w_ada_bf16 && (cond->t_dim % 64 == 0 || !cond->w_ada)) {   // bf16 weight panel: half the bytes of the HBM-bound row GEMM (fp32 accumulation + bias); a width the MFMA GEMM does not take falls back to the fp32 rows when they were given
             GemmArgs g{};
             g.X = BF(cond->c_buf_bf16); g.ldx = cond->t_dim;
             g.W = BF(cond->w_ada_bf16); g.ldw = cond->t_dim;
@@ -461,7 +461,7 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     TRY(check_plan(p));
     LDT_REQUIRE(x && x_mean && eps_tmp && coef && step_counter && n_steps > 0, LDT_EARG, "sample_loop: null pointer / n_steps");
     LDT_REQUIRE(!cond || !cond->w_ada_bf16 == !cond->c_buf_bf16, LDT_EARG, "sample_loop: w_ada_bf16 and c_buf_bf16 go together");
-    LDT_REQUIRE(!cond || (cond->temb && cond->w_ada && cond->c_buf && cond->mod_buf && cond->mod_buf == p->mod &&
+    LDT_REQUIRE(!cond || (cond->temb && (cond->w_ada || cond->w_ada_bf16) && cond->b_ada && cond->c_buf && cond->mod_buf && cond->mod_buf == p->mod &&
                           p->mod_sample_stride == cond->n_mod && cond->t_dim > 0), LDT_EARG,
                 "sample_loop: inconsistent conditioning block (plan->mod must be cond->mod_buf with sample stride n_mod)");
     hipStream_t s = ST(stream);

@@ -24,9 +24,15 @@
 #include "kernels.h"
 #include "attn_tile.h"
 
+// Round 6, Dh = 32 (the Compressor's cross-attention, BASELINE configs[3]'s microbench): LDS tiles of 128 keys = TWO joint 64-key steps per
+// barrier — both steps' S^T MFMAs are issued before the first softmax (four independent score accumulators per wave instead of
+// attn_block's one sequential chain, which, not a unit, bounded this kernel), half the barriers and staging round trips per key.
+#ifndef ATT_STREAM32_KT
+#define ATT_STREAM32_KT 128              /* tools/dbg A/B: 64 = the round-5 form (attn_block chain) */
+#endif
 template <int DH, bool OPROJ = false>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
-    constexpr int KT = 64;                      // keys per LDS tile
+__global__ __launch_bounds__(256, (DH == 32 && ATT_STREAM32_KT == 128) ? 3 : 4) void attn_fwd_kernel(const AttnArgs a) {   // (four score accumulators: 168 VGPRs)
+    constexpr int KT = (DH == 32) ? ATT_STREAM32_KT : 64;   // keys per LDS tile
     constexpr int ROWB = DH * 2;                // K / V row bytes
     constexpr int CH = ROWB / 16;               // 16-B chunks per row (8 or 4)
     constexpr int NS = DH / 16;                 // k-steps of QK^T
@@ -116,9 +122,20 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
         char* cur = smem + BUF * 2 * TILE;
         char* nxt = smem + (BUF ^ 1) * 2 * TILE;
         if (more) stage_load(Kb, a.ldk, gk_off, kv0 + KT);
-        attn_block<DH>(cur, cur + TILE, 0, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
-        if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
-        attn_block<DH>(cur, cur + TILE, 1, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+        if constexpr (KT == 128) {
+            const bool two = kv0 + 64 < a.Nk;                // (uniform) keys 64.. of the tile exist
+            f32x16 sa0, sa1, sb0, sb1;
+            attn_scores<DH>(cur, qf, sa0, sa1, lo);
+            if (two) attn_scores<DH>(cur + 64 * ROWB, qf, sb0, sb1, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<DH>(cur + TILE, sa0, sa1, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+            if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+            if (two) attn_softmax_pv<DH>(cur + TILE + 64 * ROWB, sb0, sb1, oacc, m_run, l_run, kv0 + 64, a.Nk, hh, c, lo);
+        } else {
+            attn_block<DH>(cur, cur + TILE, 0, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+            if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+            attn_block<DH>(cur, cur + TILE, 1, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
+        }
         if (more) stage_store(nxt + TILE, sv_off);
         __syncthreads();
     };
@@ -297,8 +314,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_resident_kernel(const AttnArg
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        for (int t = 0; t < ntl; ++t)
-            attn_tile<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+        if (DH == 32) attn_head_pipelined<DH>(Ks, Vs, ntl, qf, oacc, m_run, l_run, a.Nk, hh, c, lo);   // (round 6: two to four chains per wave)
+        else
+            for (int t = 0; t < ntl; ++t)
+                attn_tile<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
         // ---- normalise, stage through the wave's private LDS rows (XOR-swizzled chunks), store whole rows ----
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
@@ -456,8 +475,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_head_kernel(const AttnArgs a)
 // from L2: 64 KB of operands for 5 MFLOP, 4.2 GB of L2 traffic per launch at 1024 clouds next to 2.5 GB of HBM data.  Here one
 // workgroup owns a (cloud, head): K/V go to LDS once, each wave keeps its C/4 output channels of Wo as register fragments, and
 // the workgroup walks the head's query blocks (no barrier inside the attention; two per block around the 8 KB output stage).
+// ATT_OPROJ_FORM (tools/dbg A/B): 0 = the sequential 32-key chain of rounds 3-5 (3 waves per SIMD), 1 = the joint 64-key step (3 waves),
+// 2 = joint + pipelined across tiles (attn_head_pipelined: four score accumulators, 2 waves per SIMD)
+#ifndef ATT_OPROJ_FORM
+#define ATT_OPROJ_FORM 2
+#endif
 template <int H>   // heads: C = 32 H channels (2 or 4)
-__global__ __launch_bounds__(256, 3) void attn_oproj_resident_kernel(const AttnArgs a, int ntl) {   // (3 waves per SIMD: the prefetched Q / residual registers do not fit 128 VGPRs)
+__global__ __launch_bounds__(256, ATT_OPROJ_FORM == 2 ? 2 : 3) void attn_oproj_resident_kernel(const AttnArgs a, int ntl) {   // (the prefetched Q / residual registers do not fit 128 VGPRs)
     constexpr int DH = 32, KT = 64, ROWB = DH * 2, CH = ROWB / 16, NS = DH / 16, TILE = KT * ROWB;
     constexpr int C = H * DH, R = 128 / H, NT = C / 64, RT = R / 16, rowb = C * 2;
     extern __shared__ __attribute__((aligned(16))) char rsmem[];       // [K: ntl tiles][V: ntl tiles][O stage: R rows x C bf16 = 8 KB]
@@ -542,8 +566,15 @@ __global__ __launch_bounds__(256, 3) void attn_oproj_resident_kernel(const AttnA
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[0][i] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
+#if ATT_OPROJ_FORM == 2
+        attn_head_pipelined<DH>(Ks, Vs, ntl, qf, oacc, m_run, l_run, a.Nk, hh, c, lo);
+#elif ATT_OPROJ_FORM == 1
+        for (int t = 0; t < ntl; ++t)
+            attn_tile_joint<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+#else
         for (int t = 0; t < ntl; ++t)
             attn_tile<DH>(Ks + t * TILE, Vs + t * TILE, qf, oacc, m_run, l_run, t * KT, a.Nk, hh, c, lo);
+#endif
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         // the workgroup's 128 x Dh outputs = R whole rows of the (B*Nq, C) matrix the reference reinterprets the head-major buffer

@@ -189,6 +189,31 @@ __device__ __forceinline__ void attn_softmax_pv(const char* Vt, f32x16& s0, f32x
         }
 }
 
+// A head's resident K / V tiles (ntl x 64 keys in LDS) for one wave's 32 query rows, software-pipelined ACROSS tiles: the S^T MFMAs of tile
+// t + 1 are issued before the softmax of tile t (two score accumulator pairs that swap roles every trip: no register copies), so the
+// matrix pipe works under the wave's own softmax VALU and a wave carries two to four independent chains instead of attn_block's one —
+// the form gemm_qkv_attn256_kernel runs at Dh = 64, here for the Compressor's Dh = 32 kernels (round 6: the sequential chain, not a
+// unit, bounded them at 2-3 waves per SIMD).  Same per-tile math and summation order as attn_tile_joint.
+template <int DH>
+__device__ __forceinline__ void attn_head_pipelined(const char* Ks, const char* Vs, int ntl, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
+                                                    float& m_run, float& l_run, int Nk, int hh, float c, const AttnLaneOffs<DH>& lo) {
+    constexpr int TILE = 64 * DH * 2;
+    f32x16 sa0, sa1, sb0, sb1;
+    attn_scores<DH>(Ks, qf, sa0, sa1, lo);
+    int t = 0;
+    for (; t + 2 <= ntl; t += 2) {
+        attn_scores<DH>(Ks + (t + 1) * TILE, qf, sb0, sb1, lo);
+        __builtin_amdgcn_sched_barrier(0);
+        attn_softmax_pv<DH>(Vs + t * TILE, sa0, sa1, oacc, m_run, l_run, t * 64, Nk, hh, c, lo);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntl) attn_scores<DH>(Ks + (t + 2) * TILE, qf, sa0, sa1, lo);
+        __builtin_amdgcn_sched_barrier(0);
+        attn_softmax_pv<DH>(Vs + (t + 1) * TILE, sb0, sb1, oacc, m_run, l_run, (t + 1) * 64, Nk, hh, c, lo);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t < ntl) attn_softmax_pv<DH>(Vs + t * TILE, sa0, sa1, oacc, m_run, l_run, t * 64, Nk, hh, c, lo);   // odd count: the last tile's scores sit in the A pair
+}
+
 template <int DH>
 __device__ __forceinline__ void attn_tile_joint(const char* Kt, const char* Vt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
                                                 float& m_run, float& l_run, int kv0, int Nk, int hh, float c,

@@ -22,6 +22,9 @@
 //   EPI_RESID_F32  out fp32  = resid + gate[s,n] * (acc + bias)           (x + gate*(...), layers.py:218-219; gate may be null)
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 
 #include "kernels.h"
@@ -498,11 +501,31 @@ __device__ __forceinline__ void v2_epilogue_staged(const GemmArgs& a, f32x4 (&ac
 #ifndef V3_SCHED
 #define V3_SCHED 0                      /* 0: requests per phase 4 (W) / 2 / 2 / 0;  1: 2 / 2 / 2 / 2 (tools/dbg) */
 #endif
+#ifndef V3_XRING_BREAK
+#define V3_XRING_BREAK 1                /* tools/dbg A/B: 0 = the round-5 form (the tile loop's exit unknown to the compiler in the one-tile kernels) */
+#endif
 #define V3_BUF_BYTES 65536
 #define V3_OPER_BYTES 32768
 
-template <int EPI, int FOLD = FOLD_NONE, int XRING = 0>
+// WREG = 1 ("W from registers", round 6): the weight operand never touches LDS.  GemmArgs::Wp holds W once more in MFMA-FRAGMENT order
+// (ldt_gemm_pack_wfrag, packed once per weight version): for every 64-column band n64 and 64-deep K-tile kt the eight 16 x 32 fragments
+// (k-half h, n-tile i) as 1 KiB each, lane l's bf16x8 at + l * 16 — so a wave's whole W stream is contiguous (8 KiB per K-tile) and a
+// fragment is ONE global_load_dwordx4 with a wave-uniform base.  Per wave and K-tile: 8 register loads + 4 LDS-DMA pieces (X) + 16
+// ds_read_b128 instead of 8 pieces + 24 reads; both wave groups of a column band load the same fragments (2 x W through the L1).
+// Registers: the 256 x 256 tile leaves no room for a second full set (128 accumulators + 16 X + 64 W spills inside the K loop), so there
+// are TWO HALF-SETS of four fragments, each refilled as soon as its last MFMA has been issued: k-half 0 of K-tile s + 1 at p2 of K-tile s
+// (read at p0, s + 1), k-half 1 of K-tile s at its own p0 (read at p2): two phases between a request and its first use.  The loads are
+// asm statements with hand-counted waits like the DMA pieces (ISA lint R3); per wave and K-tile the VMEM queue is
+//     p0: Wh1(s) x4          wait vmcnt(4):  XB(s) and Wh0(s) landed       (behind them: the four loads just issued)
+//     p1: XA(s+1) x2
+//     p2: XB(s+1) x2, Wh0(s+1) x4   wait vmcnt(8):  Wh1(s) landed           (behind it: XA, XB, Wh0 of s + 1)
+//     p3:                    wait vmcnt(6):  XA(s+1) landed                 (behind it: XB(s+1), Wh0(s+1))
+// Built for the one-tile-per-workgroup residual GEMMs (XRING: fc_o, mlp.out).  Same MFMA order per accumulator: bit-identical to the LDS form.
+// KLONG is a NAME TAG only (same code): the one-tile residual GEMMs are launched as <.., .., 1, .., 1> when K >= 2048 (mlp.out) and as
+// <.., .., 1, .., 0> otherwise (fc_o), so that rocprofv3 / PMC summaries price the headline's dominant kernel under a symbol of its own.
+template <int EPI, int FOLD = FOLD_NONE, int XRING = 0, int WREG = 0, int KLONG = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a) {
+    static_assert(!WREG || (V3_PREISSUE == 1 && V3_SCHED == 0 && XRING == 1), "WREG: one tile per workgroup; the counted waits assume the pre-issue form and the 4/2/2/0 request schedule");
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -588,6 +611,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
                                              (__attribute__((address_space(3))) void*)(buf + xbds[q]), 16, 0, 0);
     };
     seek(0);
+    // WREG: this wave's fragment stream (wave-uniform position of the next K-tile to request) and the two register sets
+    const char* wrp = nullptr;                                           // K-tile whose halves are requested next
+    const char* wnext = nullptr;                                         // where the stream continues behind the tile's last K-tile
+    int w_kt = 0;
+    const int wlane = lane * 16, wlane2 = lane * 16 + 4096;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 w0[4], w1[4];                                                  // k-half 0 / 1: one fragment per n-tile
+    auto wbase = [&](int it) {
+        int m0, n0;
+        tile_of(it, m0, n0);
+        return reinterpret_cast<const char*>(a.Wp) + (long)((n0 >> 6) + wn) * nkt * 8192;
+    };
+    // (asm, not plain loads: with LDS-DMA in flight beside a register load it knows of, hipcc drains the whole queue — vmcnt(0) — in front
+    //  of the load's first use.  The destinations stay unnamed until the hand-counted wait that covers them: ISA lint R3)
+    auto wload_h0 = [&]() {
+        const unsigned long wb = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)wrp >> 32)) << 32) |
+                                 (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)wrp);   // (uniform already; pins it to SGPRs for the asm)
+#define WLD(dst, voff, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(voff), "s"(wb) : "memory")
+        WLD(w0[0], wlane, 0); WLD(w0[1], wlane, 1024); WLD(w0[2], wlane, 2048); WLD(w0[3], wlane, 3072);
+    };
+    auto wload_h1 = [&]() {
+        const unsigned long wb = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)wrp >> 32)) << 32) |
+                                 (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)wrp);
+        WLD(w1[0], wlane2, 0); WLD(w1[1], wlane2, 1024); WLD(w1[2], wlane2, 2048); WLD(w1[3], wlane2, 3072);
+#undef WLD
+        wrp += 8192;
+        if (++w_kt == nkt) { w_kt = 0; wrp = wnext; }                    // (no address arithmetic inside the K loop: wnext is ready)
+    };
+    if (WREG) wrp = wbase(0);
 
     // step-indexed (cache-cold) epilogue vectors of the FIRST tile, fetched ahead of everything else (as v2)
     const float* gate = a.gate;
@@ -607,6 +659,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 
     // prologue: K-tile 0 -> buffer 0 (and, V3_PREISSUE, K-tile 1 -> buffer 1: the invariant at every tile start is then "K-tiles 0 and 1
     // of this tile are requested", which lets a tile's SECOND K-tile be requested before the previous tile's epilogue stores — see below)
+    if (WREG) {                                                          // Wh0(0) first, then the X pieces of K-tiles 0 and 1
+        wload_h0();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_xa(smem2); issue_xb(smem2); advance();
+        issue_xa(smem2 + V3_BUF_BYTES); issue_xb(smem2 + V3_BUF_BYTES); advance();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                 // first X half of K-tile 0 landed (behind it: XB(0), XA(1), XB(1))
+    } else {
     issue_w(smem2); issue_xa(smem2); issue_xb(smem2); advance();
 #if V3_PREISSUE
     issue_w(smem2 + V3_BUF_BYTES); issue_xa(smem2 + V3_BUF_BYTES); issue_xb(smem2 + V3_BUF_BYTES); advance();
@@ -614,6 +673,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #else
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // W + first X half landed (this wave's pieces)
 #endif
+    }
     V2_BARRIER();
     if (EPI == EPI_RESID_F32) asm volatile("" : "+v"(g4_pre), "+v"(sc4_pre));
 
@@ -636,6 +696,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (WREG) wnext = wbase(it);                                     // behind its only tile the stream re-reads the first K-tile (never consumed)
         if (grp == 1) V2_BARRIER();                                      // stagger the two groups by one barrier
 
         // V3_PREISSUE: in-order VMEM retirement makes every request issued AFTER an epilogue's stores wait for them (a 128 KiB tile drains
@@ -649,14 +710,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             char* nb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;            // buffer being refilled (K-tile gk + 1)
             bf16x8 wf[4], xf[4];
             // ---------------- p0: half 0 — W (4 n-tiles) + X m-tiles 0..3; DMA: W of the next K-tile; wait: this K-tile's X rows 64.. ----------------
+            if (!WREG) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb0 + i * 2048);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb0 + i * 2048);
 #if V3_SCHED == 1
             issue_w(nb, 0, 2);                                           // balanced form: 2 pieces per wave in every phase (tools/dbg A/B)
 #else
-            if (!SKIP) issue_w(nb);
+            if (WREG) wload_h1();                                        // k-half 1 of THIS K-tile (its registers were last read at the previous p3)
+            else if (!SKIP) issue_w(nb);
 #endif
             if (FL & KT_FOLD_DMA) {
                 if (wave < 2 * a.stats_parts) {
@@ -673,11 +737,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             if ((FL & KT_FOLD_FINAL) && wave < 4) v2_fold_finalize(smem2 + V2_RING_BYTES, tid, a.stats_parts, a.K);
             // requests issued after this K-tile's second X half (the data this wait is for): none / W of the next K-tile / (KT_FIRST with
             // V3_PREISSUE) the whole pre-requested K-tile 1; after an epilogue also its stores (clamped to the 6-bit counter: only stricter)
-            constexpr int P0W = SKIP ? 8 : V3_SCHED == 1 ? 2 : 4;
-            constexpr bool AFTER_EPI = (FL & KT_FIRST) || (V3_PREISSUE && (FL & KT_SECOND));
+            // WREG (header): behind XB(s) and Wh0(s) sit the four loads of this p0; KT_FIRST: + the pre-requested X pieces of K-tile 1
+            constexpr int P0W = WREG ? (SKIP ? 8 : 4) : SKIP ? 8 : V3_SCHED == 1 ? 2 : 4;
+            constexpr bool AFTER_EPI = (FL & KT_FIRST) || (V3_PREISSUE && !WREG && (FL & KT_SECOND));
             if (AFTER_EPI && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W + EPI_VMEM > 63 ? 63 : P0W + EPI_VMEM) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P0W) : "memory");
             V2_BARRIER();
+            if (WREG) {                                                  // the half-set becomes visible to the compiler only behind its covering wait
+                asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, w0[i]);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
@@ -704,8 +774,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             __builtin_amdgcn_s_setprio(0);
             V2_BARRIER();
             // ---------------- p2: half 1 — W + X m-tiles 0..3; DMA: second X half of the next K-tile ----------------
+            if (!WREG) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(st + wb1 + i * 2048);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(st + xb1 + i * 2048);
 #if V3_SCHED == 1
@@ -713,7 +785,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #else
             if (!SKIP) { issue_xb(nb); advance(); }
 #endif
+            if (WREG) {                                                  // k-half 0 of the NEXT K-tile (p1's MFMAs were the last readers); then Wh1(s) landed
+                wload_h0();
+                if (SKIP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (KT_FIRST requested no X piece: only Wh0(s+1) is younger)
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
             V2_BARRIER();
+            if (WREG) {
+                asm volatile("" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, w1[i]);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
@@ -729,8 +811,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             issue_xb(nb);
             advance();
 #endif
-            if (SKIP && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + EPI_VMEM > 63 ? 63 : 2 + EPI_VMEM) : "memory");   // W + X half of K-tile 1: older than the stores
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // (WREG: behind XA(s+1) sit XB(s+1) and the four Wh0(s+1) loads of p2; KT_FIRST: K-tile 1 is older than everything p2 waited for)
+            constexpr int P3W = WREG ? (SKIP ? 4 : 6) : 2;
+            if (!WREG && SKIP && prev_staged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + EPI_VMEM > 63 ? 63 : 2 + EPI_VMEM) : "memory");   // W + X half of K-tile 1: older than the stores
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P3W) : "memory");
             V2_BARRIER();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -743,7 +827,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             ++gk;
         };
 #define KTL(f) std::integral_constant<int, (f)>{}
-        if (FOLD == FOLD_CONSUMER) {                                     // K >= 256 (launcher): at least 4 K-tiles
+        if (FOLD == FOLD_CONSUMER) {                              // K >= 256 (launcher): at least 4 K-tiles
             ktile(KTL(KT_FIRST)); ktile(KTL(KT_FOLD_DMA | KT_SECOND)); ktile(KTL(KT_PLAIN)); ktile(KTL(KT_FOLD_FINAL));
             for (int kt = 4; kt < nkt; ++kt) ktile(KTL(KT_PLAIN));
         } else {
@@ -757,7 +841,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
 #if V3_PREISSUE
         if (!XRING) {                                                    // K-tile 1 of the next tile -> the buffer the last K-tile has just left (all waves are past its reads)
             char* pb = smem2 + ((gk + 1) & 1) * V3_BUF_BYTES;
-            issue_w(pb); issue_xa(pb); issue_xb(pb); advance();
+            if (!WREG) issue_w(pb);
+            issue_xa(pb); issue_xb(pb); advance();
         }
 #endif
         if (XRING) {
@@ -765,6 +850,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_256f_kernel(const GemmArgs a
             V2_BARRIER();
             v2_epilogue_staged<EPI, FOLD, 1>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
                                                 true, g4_pre, sc4_pre, smem2 + wave * 16384);
+#if V3_XRING_BREAK
+            break;                                                       // (launcher: one tile per workgroup — nothing of the stream state is live past here: -13 spilled VGPRs)
+#else
+            if (WREG) break;
+#endif
         } else
             v2_epilogue_staged<EPI, FOLD>(a, acc, m0, n0, grp, wn, lane, lrow, lchk, gate, stage_reg, smem2 + V2_RING_BYTES, ln_scale,
                                           it == 0 && (pre_ok || FOLD == FOLD_PRODUCER), g4_pre, sc4_pre);
@@ -1111,6 +1201,43 @@ __global__ __launch_bounds__(512) void gemm_qkv_attn256_kernel(const GemmArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- W in MFMA-fragment order for the WREG form of the 256-tile kernel: Wp[((n64 * (K/64) + kt) * 8 + h * 4 + i) * 64 + lane][8] =
+// W[n64 * 64 + i * 16 + (lane & 15)][kt * 64 + h * 32 + (lane >> 4) * 8 .. + 8]   (one thread per 16-byte chunk)
+__global__ __launch_bounds__(256) void pack_wfrag_kernel(const bf16_t* __restrict__ W, long ldw, int N, int K, bf16_t* __restrict__ Wp) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;                 // chunk index in Wp
+    const int nkt = K >> 6;
+    if (c >= (long)N * K / 8) return;
+    const int lane = (int)(c & 63), f = (int)((c >> 6) & 7);
+    const long t = c >> 9;                                               // n64 * nkt + kt
+    const int kt = (int)(t % nkt), n64 = (int)(t / nkt);
+    const int n = n64 * 64 + (f & 3) * 16 + (lane & 15), k = kt * 64 + (f >> 2) * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<bf16x8*>(Wp + c * 8) = *reinterpret_cast<const bf16x8*>(W + (long)n * ldw + k);
+}
+int ldt_gemm_pack_wfrag_launch(const bf16_t* W, long ldw, int N, int K, bf16_t* Wp, hipStream_t stream) {
+    LDT_REQUIRE(W && Wp && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0 && ldw >= K && ldw % 8 == 0 && ldt_aligned16(W) && ldt_aligned16(Wp), LDT_ESHAPE,
+                "pack_wfrag: N=%d and K=%d must be multiples of 64, rows 16-byte aligned (ldw=%ld)", N, K, ldw);
+    const long chunks = (long)N * K / 8;
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, W, ldw, N, K, Wp);
+    return ldt_check_launch("pack_wfrag");
+}
+// tools/dbg + tests: ldt_dbg_gemm_wreg(1) makes every 256-tile launch WITHOUT a caller-packed Wp pack its W on the fly into a cache keyed by
+// (pointer, shape) — never invalidated: the caller must not change those weights afterwards.  The product path passes Wp itself.
+static std::atomic<int> g_dbg_wreg{-1};
+extern "C" int ldt_dbg_gemm_wreg(int32_t on) { g_dbg_wreg.store(on); return LDT_OK; }
+static const bf16_t* dbg_wfrag_cached(const bf16_t* W, long ldw, int N, int K, hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::tuple<const void*, long, int, int>, bf16_t*> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_tuple((const void*)W, ldw, N, K);
+    auto itc = cache.find(key);
+    if (itc != cache.end()) return itc->second;
+    bf16_t* wp = nullptr;
+    if (hipMalloc((void**)&wp, (size_t)N * K * 2) != hipSuccess) return nullptr;
+    if (ldt_gemm_pack_wfrag_launch(W, ldw, N, K, wp, stream) != LDT_OK) { (void)hipFree(wp); return nullptr; }
+    cache[key] = wp;
+    return wp;
+}
+
 // rows per group of the grouped tile order (tools/dbg sets it at run time; LDT_GEMM_GM at start-up)
 static std::atomic<int> g_group_m{-1};
 extern "C" int ldt_dbg_gemm_group_m(int32_t gm) { g_group_m.store(gm); return LDT_OK; }
@@ -1144,14 +1271,27 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     a_copy.dbg = g_dbg_epi.load() >= 0 ? g_dbg_epi.load() : dbg_env;
     const GemmArgs* a = &a_copy;
     LDT_REQUIRE(gemm256_takes(EPI, a), LDT_ESHAPE, "gemm256: M=%d N=%d must be multiples of 256, K=%d of 64 (>= 128), rows 16-byte aligned", a->M, a->N, a->K);
+    // W from registers (kernel <.., .., 1, 1>: the one-tile-per-workgroup residual GEMMs): the caller's fragment-order copy
+    constexpr bool WREG_BUILT = (EPI == EPI_RESID_F32);
+    static const int wreg_env = getenv("LDT_GEMM_WREG") ? atoi(getenv("LDT_GEMM_WREG")) : -1;      // 0: off even when Wp is given; 1: pack on the fly (tools/dbg)
+    const int wreg_dbg = g_dbg_wreg.load() >= 0 ? g_dbg_wreg.load() : wreg_env;
     const int tiles = tm * tn;
     static const int cap = getenv("LDT_GEMM_GRID") ? atoi(getenv("LDT_GEMM_GRID")) : LDT_NUM_CUS;   // tools/dbg: > 256 = non-persistent
     const int lim = (a->max_wgs > 0 && a->max_wgs < cap) ? a->max_wgs : cap;
     const int grid = tiles < lim ? tiles : lim;                          // one persistent workgroup per CU (or per CU of this stream's share)
     if constexpr (EPI == EPI_RESID_F32) {
         if (xring && grid == tiles && a->dbg == 0) {                     // every workgroup has exactly one tile: the ring is idle in its epilogue
-            LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), V2_LDS_BYTES, "gemm256f");
-            hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);
+            if (WREG_BUILT && wreg_dbg == 1 && !a_copy.Wp) a_copy.Wp = dbg_wfrag_cached(a->W, a->ldw, a->N, a->K, stream);
+            const bool wreg = WREG_BUILT && a_copy.Wp && wreg_dbg != 0 && ldt_aligned16(a_copy.Wp);
+            const bool klong = a->K >= 2048;                             // symbol tag: mlp.out vs fc_o (see the kernel's template comment)
+#define LAUNCH_XR(W, KL)                                                                                                          \
+    do {                                                                                                                          \
+        LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1, W, KL>), V2_LDS_BYTES, "gemm256f");                                \
+        hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1, W, KL>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);     \
+    } while (0)
+            if (wreg) { if (klong) LAUNCH_XR(1, 1); else LAUNCH_XR(1, 0); }
+            else { if (klong) LAUNCH_XR(0, 1); else LAUNCH_XR(0, 0); }
+#undef LAUNCH_XR
             return ldt_check_launch("gemm_bf16_nt_256f");
         }
     }

@@ -7,15 +7,18 @@ loads hipcc does not count (their destination VGPRs must stay untouched until th
 registers an MFMA in flight still reads as its C operand (profiles/r04_mid_epilogue_hazard.txt).  This tool disassembles the gfx950
 code objects embedded in the library (`.hip_fatbin` -> clang offload bundles -> ELF -> llvm-objdump -d) and checks, per kernel:
 
-  R1  no scratch, no register spills (`.private_segment_fixed_size`, `.vgpr_spill_count`, `.sgpr_spill_count` of the code object's
-      metadata) in every kernel of the GUARDED families: a spill / reload beside asm loads moves registers whose data has not arrived.
+  R1  scratch / register spills (`.private_segment_fixed_size`, `.vgpr_spill_count`, `.sgpr_spill_count` of the code object's metadata)
+      of every kernel of the GUARDED families: none in a kernel with asm-issued register loads (a spill / reload beside them moves
+      registers whose data has not arrived), and elsewhere no more than the audited amount recorded in isa_signatures.json ("scratch":
+      a few multi-tile 256-tile forms spill 3-20 VGPRs around their epilogues).  (Rounds 4-5 read these keys without their leading dot,
+      so the rule never fired: round 6 found 13 spilled VGPRs in the headline's dominant kernel that way and removed them.)
   R2  the VMEM / wait FINGERPRINT of every guarded kernel — the ordered sequence of [load, LDS-DMA load, store, `s_waitcnt vmcnt(N)`
       with its immediate, s_barrier, branch] events — equals the audited one in isa_signatures.json.  The counted waits were derived
       from exactly that sequence; any change (a compiler that reorders, merges, splits or adds a VMEM op or a wait) must be re-audited
       by a human: read the diff printed here against the kernel's comments, then `python isa_lint.py --update libldt_hip.so`.
   R3  asm-load safety, the kernels of ASM_LOADS (register loads issued by `asm volatile`): between such a load and the first `s_waitcnt vmcnt(N)` that covers it (N <= the
       number of VMEM ops issued after it on every path), no instruction names one of its destination registers (a copy, spill or reuse
-      of a register whose data is still in flight).  Program-order scan through forward branches; stops at a loop boundary.
+      of a register whose data is still in flight).  Walks the control-flow graph, loops included (check_asm_load_safety).
   R4  MFMA-C hazard, the mid-tile GEMM family: the fence between the main loop and the epilogue (4 x `s_nop 15` between two scheduling
       barriers: LDS data returning into registers that MFMAs in flight still name, profiles/r04_mid_epilogue_hazard.txt) is present and
       sits where the source put it: directly downstream of the main loop's last MFMA, no LDS read in between.
@@ -42,6 +45,7 @@ GUARDED = [r"gemm_bf16_nt_256f_kernel<", r"gemm_qkv_attn256_kernel<", r"gemm_bf1
 MFMA_C_FAMILIES = [r"gemm_bf16_nt_mid_kernel<"]
 # register-destination loads issued by `asm volatile` (hipcc neither counts nor waits for them): (kernel regex, mnemonic, source site)
 ASM_LOADS = [(r"attn_fwd_head_kernel<", "global_load_dwordx4", "attention.hip: the Q fragments"),
+             (r"gemm_bf16_nt_256f_kernel<\d+, \d+, 1, 1, \d+>", "global_load_dwordx4", "gemm_bf16.hip WREG: the W fragment half-sets"),
              (r"gemm_bf16_nt_mid_kernel<\d+, \d+, \d+, 2, \d+>", "global_load_dwordx2", "gemm_mid.hip mid_loader: the row-statistics partials")]
 
 
@@ -176,37 +180,19 @@ def fingerprint(ins_list):
     return " ".join(ev)
 
 
-def forward_regions(ins_list):
-    """Structured control flow as hipcc emits it: a FORWARD branch at i to the instruction at t skips (i, t).  Returns (inside, loop_head):
-    inside[j] = frozenset of the skip regions containing j (instructions that do not execute on every path through the enclosing
-    straight-line code), loop_head[j] = True where a BACKWARD branch lands (program order is not execution order past it)."""
-    idx = {ins.addr: k for k, ins in enumerate(ins_list)}
-    n = len(ins_list)
-    regs, loop_head = [], [False] * n
-    for k, ins in enumerate(ins_list):
-        if ins.target is not None and ins.target in idx:
-            t = idx[ins.target]
-            if t > k:
-                regs.append((k, t))
-            else:
-                loop_head[t] = True
-    inside = [set() for _ in range(n)]
-    for r, (k, t) in enumerate(regs):
-        for j in range(k + 1, t):
-            inside[j].add(r)
-    forward_regions.idx = idx
-    return [frozenset(x) for x in inside], loop_head
-
-
 def check_asm_load_safety(name, ins_list, tally=None, mnemonic=None):
-    """R3: destination registers of a register load stay unnamed until the covering wait.  Forward branches are followed in program
-    order: VMEM ops and waits inside a conditionally skipped region the load is not itself part of do not count (a lower bound on the
-    requests younger than the load on every path), every instruction on any path is checked for naming a destination.  `tally` counts
-    the loads whose covering wait was found ("covered") and those whose scan ended at a loop boundary / the kernel's end ("open")."""
+    """R3: destination registers of a register load stay unnamed until a wait that covers it, on EVERY path.  The instruction list is
+    walked as a control-flow graph (fall-through + branch targets, back edges included): a state is (instruction, number of VMEM ops
+    issued behind the load so far); `s_waitcnt vmcnt(N)` with N <= that number ends a path as covered; any instruction that names a
+    destination register before that is a violation (a copy, spill or reuse of a register whose data is still in flight).  The count only
+    grows along a path and a smaller count is the harder case, so an instruction is revisited only with a smaller count than before:
+    loops terminate.  Branch conditions are not correlated (every successor of a conditional branch is followed): conservative.
+    `tally` counts the loads by verdict: "covered" (on every path), "open" (some path reaches the end of the kernel without a covering
+    wait: an error for the asm-issued families), "violation"."""
     errs = []
     n = len(ins_list)
     tally = tally if tally is not None else {}
-    inside, loop_head = forward_regions(ins_list)
+    idx = {ins.addr: k for k, ins in enumerate(ins_list)}
     for k, ins in enumerate(ins_list):
         if not (is_vmem(ins.op) and "load" in ins.op) or is_lds_dma(ins) or (mnemonic is not None and ins.op != mnemonic):
             continue
@@ -214,44 +200,52 @@ def check_asm_load_safety(name, ins_list, tally=None, mnemonic=None):
         dst = regs_of(first)
         if not dst:
             continue
-        after = 0
-        verdict = "open"
-        idx = forward_regions.idx
-        j = k
-        while j + 1 < min(n, k + 6000):
-            j += 1
-            x = ins_list[j]
-            if loop_head[j] or x.op.startswith(("s_endpgm", "s_setpc")):
-                break
-            if x.op == "s_branch" and x.target is not None and x.target > x.addr and inside[j] <= inside[k] and x.target in idx:
-                j = idx[x.target] - 1                       # an unconditional forward branch on the load's own path: the skipped
-                continue                                    # instructions (the other arm of an if / else) do not follow this load
-            if x.target is not None and not (x.target > x.addr):
-                break                                       # a backward branch: the loop's body may run again
-            always = inside[j] <= inside[k]                 # executes whenever the code behind the load does
-            w = vmcnt_of(x)
-            if w is not None and always and w <= after:
-                verdict = "covered"
-                break
-            if is_vmem(x.op):
-                # a younger LOAD into the same registers is ordered behind this one by the hardware (VMEM returns in order; exec-masked
-                # if / else arms load disjoint lanes of one register): only its address operands are checked
-                named = regs_of(x.text.split(",", 1)[1] if ("load" in x.op and "," in x.text) else x.text)
-                if named & dst:
+        best = {}                                           # instruction -> smallest count it was entered with
+        stack = [(k + 1, 0)]
+        verdict = "covered"
+        while stack and verdict != "violation":
+            j, after = stack.pop()
+            while True:
+                if j >= n:
+                    verdict = "open"
+                    break
+                if best.get(j, 1 << 30) <= after:
+                    break
+                best[j] = after
+                x = ins_list[j]
+                if x.op.startswith(("s_endpgm", "s_setpc")):
+                    verdict = "open" if verdict == "covered" else verdict
+                    break
+                w = vmcnt_of(x)
+                if w is not None and w <= after:
+                    break                                   # covered on this path
+                if is_vmem(x.op):
+                    # a younger LOAD into the same registers is ordered behind this one by the hardware (VMEM returns in order; exec-masked
+                    # if / else arms load disjoint lanes of one register): only its address operands are checked
+                    named = regs_of(x.text.split(",", 1)[1] if ("load" in x.op and "," in x.text) else x.text)
+                    if named & dst:
+                        errs.append("%s: `%s` names a register of `%s` before the wait that covers the load" % (name, x.text, ins.text))
+                        verdict = "violation"
+                        break
+                    after += 1
+                elif x.op.startswith(("s_cbranch", "s_branch")):
+                    t = idx.get(x.target) if x.target is not None else None
+                    if t is None:
+                        errs.append("%s: R3: branch `%s` behind `%s` has no resolvable target" % (name, x.text, ins.text))
+                        verdict = "violation"
+                        break
+                    if x.op == "s_branch":
+                        j = t
+                        continue
+                    stack.append((t, after))                # conditional: the taken arm later, the fall-through now
+                elif x.op not in ("s_nop", "s_waitcnt", "s_barrier", "s_sleep", "s_setprio") and regs_of(x.text) & dst:
                     errs.append("%s: `%s` names a register of `%s` before the wait that covers the load" % (name, x.text, ins.text))
                     verdict = "violation"
                     break
-                after += 1 if always else 0
-                continue
-            if x.op in ("s_nop", "s_waitcnt", "s_barrier", "s_sleep", "s_setprio") or x.op.startswith(("s_cbranch", "s_branch")):
-                continue
-            if regs_of(x.text) & dst:
-                errs.append("%s: `%s` names a register of `%s` before the wait that covers the load" % (name, x.text, ins.text))
-                verdict = "violation"
-                break
+                j += 1
         tally[verdict] = tally.get(verdict, 0) + 1
         if verdict == "open" and mnemonic is not None:
-            errs.append("%s: R3: no covering `s_waitcnt vmcnt` found in program order behind the asm-issued `%s`" % (name, ins.text))
+            errs.append("%s: R3: a path behind the asm-issued `%s` reaches the end of the kernel without a covering `s_waitcnt vmcnt`" % (name, ins.text))
     return errs
 
 
@@ -280,9 +274,28 @@ def check_mfma_c_hazard(name, ins_list):
     return errs
 
 
+def toolchain_id():
+    """The compiler the fingerprints depend on: first line of `clang --version` of the LLVM the library was built with."""
+    try:
+        out = subprocess.run([os.path.join(LLVM, "clang"), "--version"], capture_output=True, text=True, check=True).stdout
+        return out.strip().splitlines()[0]
+    except (OSError, subprocess.CalledProcessError, IndexError):
+        return None
+
+
+def load_gold():
+    try:
+        return json.load(open(SIG_FILE))
+    except (OSError, ValueError):
+        return None
+
+
 def analyse(lib):
     fps, errs, nk = {}, [], 0
     analyse.tally = {}
+    analyse.scratch = {}
+    gold_doc = load_gold() or {}
+    analyse.audited_scratch = gold_doc.get("scratch", {})
     for elf in code_objects(lib):
         kernels, meta = disassemble(elf)
         names = demangle(list(kernels))
@@ -295,9 +308,14 @@ def analyse(lib):
                 if m is None:
                     errs.append("%s: no metadata entry found (R1 cannot be checked)" % name)
                 else:
-                    for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count"):
-                        if m.get(key, 0) != 0:
-                            errs.append("%s: %s = %d (R1: the guarded kernels must not spill or use scratch)" % (name, key, m[key]))
+                    has_asm_loads = any(re.search(pat, name) for pat, _m, _s in ASM_LOADS)
+                    used = {key: int(m.get("." + key, 0)) for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count")}
+                    analyse.scratch[name] = used["private_segment_fixed_size"]
+                    allowed = 0 if has_asm_loads else analyse.audited_scratch.get(name, 0)
+                    if used["private_segment_fixed_size"] > allowed or (has_asm_loads and (used["vgpr_spill_count"] or used["sgpr_spill_count"])):
+                        errs.append("%s: scratch %d B, %d VGPRs / %d SGPRs spilled (R1: audited %d B%s)" % (
+                            name, used["private_segment_fixed_size"], used["vgpr_spill_count"], used["sgpr_spill_count"], allowed,
+                            "; kernels with asm-issued register loads must not spill at all" if has_asm_loads else ""))
                 fps[name] = fingerprint(ins_list)
             for pat, mnem, _site in ASM_LOADS:
                 if re.search(pat, name):
@@ -321,29 +339,46 @@ def main(argv):
         return 0
     update = "--update" in argv
     lib = [a for a in argv if not a.startswith("--")][0]
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        # without the disassembler nothing can be checked: say so loudly, do not fail a correct library's build
+        print("isa_lint: WARNING: %s/llvm-objdump not found — the hand-counted kernels of %s were NOT checked (set LDT_LLVM_BIN)" % (LLVM, lib), file=sys.stderr)
+        return 0
     fps, errs, nk = analyse(lib)
+    warns = []
+    tc = toolchain_id()
     if update:
         with open(SIG_FILE, "w") as f:
             json.dump({"what": "audited VMEM / wait fingerprints of the guarded kernels (isa_lint.py R2); L load, D LDS-DMA load, S store, A atomic, "
-                               "Wn s_waitcnt vmcnt(n), | s_barrier, b branch", "kernels": fps}, f, indent=1, sort_keys=True)
-        print("isa_lint: wrote %d fingerprints to %s" % (len(fps), SIG_FILE))
+                               "Wn s_waitcnt vmcnt(n), | s_barrier, b branch; `scratch`: audited scratch bytes of the guarded kernels that spill (R1); "
+                               "`toolchain`: the compiler these were audited on",
+                       "toolchain": tc, "scratch": {k: v for k, v in sorted(analyse.scratch.items()) if v}, "kernels": fps}, f, indent=1, sort_keys=True)
+        print("isa_lint: wrote %d fingerprints to %s (toolchain: %s)" % (len(fps), SIG_FILE, tc))
     else:
-        try:
-            gold = json.load(open(SIG_FILE))["kernels"]
-        except (OSError, ValueError, KeyError):
-            gold = None
+        doc = load_gold()
+        gold = doc.get("kernels") if doc else None
+        if gold is None:
             errs.append("R2: %s is missing or unreadable (run isa_lint.py --update after auditing the kernels)" % SIG_FILE)
-        if gold is not None:
+        else:
+            # the fingerprints are a function of the compiler's schedule: on ANOTHER toolchain than the audited one a difference is a
+            # prompt to re-audit (warning), not a broken build — the hazard rules R1 / R3 / R4 are checked on the binary itself and stay fatal
+            same_tc = doc.get("toolchain") is None or tc is None or doc.get("toolchain") == tc
+            sink = errs if same_tc else warns
             for k in sorted(set(gold) | set(fps)):
                 if k not in fps:
-                    errs.append("R2: audited kernel %s is no longer in the library (re-audit, then --update)" % k)
+                    sink.append("R2: audited kernel %s is no longer in the library (re-audit, then --update)" % k)
                 elif k not in gold:
-                    errs.append("R2: guarded kernel %s has no audited fingerprint (audit it, then --update)" % k)
+                    sink.append("R2: guarded kernel %s has no audited fingerprint (audit it, then --update)" % k)
                 elif gold[k] != fps[k]:
                     a, b = gold[k].split(), fps[k].split()
                     d = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
-                    errs.append("R2: VMEM / wait fingerprint of %s changed at event %d: audited `... %s` now `... %s` (re-audit the hand-counted "
+                    sink.append("R2: VMEM / wait fingerprint of %s changed at event %d: audited `... %s` now `... %s` (re-audit the hand-counted "
                                 "waits of this kernel, then --update)" % (k, d, " ".join(a[max(0, d - 6):d + 6]), " ".join(b[max(0, d - 6):d + 6])))
+            if warns:
+                print("isa_lint: WARNING: built with `%s`, fingerprints audited on `%s`: %d fingerprint difference(s) NOT treated as errors.  Re-audit: "
+                      "`python3 isa_lint.py --dump REGEX lib` against the kernels' comments, run the -m gpu suite (bit-equality and soak tests), then "
+                      "`python3 isa_lint.py --update lib`." % (tc, doc.get("toolchain"), len(warns)), file=sys.stderr)
+                for w in warns[:10]:
+                    print("  " + w, file=sys.stderr)
     if errs:
         print("isa_lint: %d violation(s) in %s" % (len(errs), lib), file=sys.stderr)
         for e in errs[:60]:

@@ -34,6 +34,8 @@ struct GemmArgs {
     bf16_t* attn_o; float attn_scale_log2e;
     // fused q projection + cross-attention (gemm_mid.hip, ldt_gemm_mid_q_xattn_try): the condition's cached K | V rows (elements)
     const bf16_t* attn_k; const bf16_t* attn_v; long attn_ldkv; long attn_kv_batch_stride;
+    // 256-tile kernel, WREG form: W once more in MFMA-fragment order (gemm_bf16.hip "W from registers"; ldt_gemm_pack_wfrag), nullable
+    const bf16_t* Wp;
 };
 
 struct LnArgs {

@@ -204,8 +204,11 @@ class DiffusionBase:
             else:
                 extra, kv, S = model.condition_embedding(label, condition)            # per-sample rows, rebuilt every step
                 temb = model.time_embedding(ts.to(dev))
-                w_ada, b_ada = model.stacked_adaln()
-                w_ada_bf = model.stacked_adaln_bf16() if int(os.environ.get("LDT_ADALN_BF16", "1")) else None
+                panel = model.stacked_adaln_bf16() if int(os.environ.get("LDT_ADALN_BF16", "1")) else None
+                if panel is not None:                                                 # bf16 weight panel (t_dim % 64 == 0); no fp32 copy kept
+                    (w_ada_bf, b_ada), w_ada = panel, None
+                else:
+                    (w_ada, b_ada), w_ada_bf = model.stacked_adaln(), None
             bounds = [B * i // streams for i in range(streams + 1)]
             jobs, keep = [], []
             fold = None
@@ -233,10 +236,10 @@ class DiffusionBase:
                     kvs = None if kv is None else {l: t.view(B, S, -1)[lo:hi].reshape(Bs * S, -1) for l, t in kv.items()}
                     plan = model.plan(Bs, T, modb, 0, model.n_mod, kv_cond=kvs, cond_tokens=S, slot=i, gemm_wgs=wgs)
                     c_bf = None if w_ada_bf is None else torch.empty((Bs, model.t_dim), dtype=torch.bfloat16, device=dev)
-                    cond = CondArgs(temb.data_ptr(), ops._p(ex), w_ada.data_ptr(), b_ada.data_ptr(), c_buf.data_ptr(),
+                    cond = CondArgs(temb.data_ptr(), ops._p(ex), ops._p(w_ada), b_ada.data_ptr(), c_buf.data_ptr(),
                                     modb.data_ptr(), model.t_dim, model.n_mod, ops._p(w_ada_bf), ops._p(c_bf))
                     cond_ref = ctypes.byref(cond)
-                    keep.append((ex, kvs, c_buf, modb, cond, c_bf, w_ada_bf))
+                    keep.append((ex, kvs, c_buf, modb, cond, c_bf, w_ada_bf, w_ada, b_ada))
                 if nz is not None and streams > 1:
                     nz = nz.contiguous()                                              # [N, Bs, T, z] with step stride Bs*T*z
                 jobs.append((plan, xs, xm, eps_tmp, counter, nz, cond_ref, elem_offset + lo * int(np.prod(shape)), tj))
@@ -459,15 +462,6 @@ class DiffusionSubVPSDE(DiffusionBase):
     def e2int_f(self, t):
         return torch.exp(-0.5 * self.beta_start * t - 0.25 * (self.beta_end - self.beta_start) * t * t)
 
-    def var_vpsde(self, t):
-        return 1.0 - (1.0 - self.sigma2_0) * torch.exp(
-            -self.beta_start * t - 0.5 * (self.beta_end - self.beta_start) * t * t)
-
-    def inv_var_vpsde(self, var):
-        c = torch.log((1 - var) / (1 - self.sigma2_0))
-        a = self.beta_end - self.beta_start
-        return (-self.beta_start + torch.sqrt(np.square(self.beta_start) - 2 * a * c)) / a
-
 
 class _GeometricVariance(DiffusionBase):
     """var(t) = sigma2_min (sigma2_max / sigma2_min)^t - sigma2_min + sigma2_0, shared by the VE and the geometric SDE."""
@@ -483,10 +477,6 @@ class _GeometricVariance(DiffusionBase):
 
     def var(self, t):
         return self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t) - self.sigma2_min + self.sigma2_0
-
-    def inv_var(self, var):
-        return torch.log((var + self.sigma2_min - self.sigma2_0) / self.sigma2_min) / np.log(
-            self.sigma2_max / self.sigma2_min)
 
 
 class DiffusionVESDE(_GeometricVariance):
@@ -504,12 +494,6 @@ class DiffusionVESDE(_GeometricVariance):
 
     def e2int_f(self, t):
         return torch.ones_like(t)
-
-    def var_N(self, t):
-        return 1.0 - self.sigma2_min + self.sigma2_min * ((self.sigma2_max / self.sigma2_min) ** t)
-
-    def inv_var_N(self, var):
-        return torch.log((var + self.sigma2_min - 1.0) / self.sigma2_min) / np.log(self.sigma2_max / self.sigma2_min)
 
 
 class DiffusionGeometric(_GeometricVariance):

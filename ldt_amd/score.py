@@ -149,12 +149,18 @@ class Score(nn.Module):
         """The stacked adaLN weights as a bf16 panel [n_mod][t_dim] (ldt_cond_args.w_ada_bf16): the per-step per-sample AdaLN rows of
         the conditional sampler are HBM-bound on their weights (BASELINE configs[4]: 604 MB fp32 per step, 163 us = 9 % of a step;
         80 us as bf16 — profiles/r05_adaln_bf16_probe.txt), and bf16 operands with fp32 accumulation are what every token GEMM of the
-        model already runs on.  LDT_ADALN_BF16=0 keeps the fp32 SGEMM (the rows then equal the reference's fp32 Linear to 1e-12)."""
+        model already runs on.  LDT_ADALN_BF16=0 keeps the fp32 SGEMM (the rows then equal the reference's fp32 Linear to 1e-12).
+        -> (panel, bias), or None when the MFMA row GEMM does not take this width (t_dim % 64 != 0: the fp32 SGEMM takes any).  The fp32
+        stack is dropped once the panel exists (the loop needs one of the two, include/ldt_hip.h ldt_cond_args)."""
+        if self.t_dim % 64 != 0:
+            return None
         P = self.packed()
         if "w_ada_bf16" not in P:
-            w_ada, _ = self.stacked_adaln()
+            w_ada, b_ada = self.stacked_adaln()
             P["w_ada_bf16"] = ops.cast_pad_bf16(w_ada, w_ada.shape[1])
-        return P["w_ada_bf16"]
+            P["b_ada_only"] = b_ada
+            P.pop("w_ada", None)                                         # 604 MB at the shipped width; rebuilt on demand by stacked_adaln()
+        return P["w_ada_bf16"], P["b_ada_only"]
 
     def time_embedding(self, t):
         """TimeEmbedding(t) only: t [n] -> c [n, t_dim] fp32 (model/layers.py:38-41)."""

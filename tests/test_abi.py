@@ -96,7 +96,21 @@ def test_isa_lint_catches_what_it_is_for():
     moved = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "v_mov_b32 v9, v4", "s_waitcnt vmcnt(0)"])
     assert len(L.check_asm_load_safety("k", moved, {}, "global_load_dwordx2")) == 1
     short = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "global_load_lds_dwordx4 v[6:7], off", "s_waitcnt vmcnt(2)", "s_endpgm"])
-    assert any("no covering" in e for e in L.check_asm_load_safety("k", short, {}, "global_load_dwordx2"))
+    assert any("without a covering" in e for e in L.check_asm_load_safety("k", short, {}, "global_load_dwordx2"))
+    # control flow: a load whose covering wait sits behind a loop's back edge is followed around the loop (covered: the second load of the
+    # next trip is the one request behind it), and a destination named on ONE arm of a branch before that wait is found
+    def loop(body):
+        ins = mk(["s_mov_b32 s0, 4"] + body + ["s_sub_u32 s0, s0, 1", "s_cbranch_scc1 back", "s_waitcnt vmcnt(0)", "s_endpgm"])
+        ins[-3].target = ins[1].addr                                     # back edge to the first instruction of the body
+        return ins
+    carried = loop(["s_waitcnt vmcnt(1)", "v_add_f32 v8, v4, v5", "global_load_dwordx2 v[4:5], v[2:3], off", "global_load_lds_dwordx4 v[6:7], off"])
+    t = {}
+    assert L.check_asm_load_safety("k", carried, t, "global_load_dwordx2") == [] and t == {"covered": 1}
+    early = loop(["v_add_f32 v8, v4, v5", "s_waitcnt vmcnt(1)", "global_load_dwordx2 v[4:5], v[2:3], off", "global_load_lds_dwordx4 v[6:7], off"])
+    assert len(L.check_asm_load_safety("k", early, {}, "global_load_dwordx2")) == 1
+    arm = mk(["global_load_dwordx2 v[4:5], v[2:3], off", "s_cbranch_vccz skip", "v_mov_b32 v9, v5", "s_waitcnt vmcnt(0)", "s_endpgm"])
+    arm[1].target = arm[3].addr
+    assert len(L.check_asm_load_safety("k", arm, {}, "global_load_dwordx2")) == 1
     assert L.fingerprint(ok) == "L D W1" and L.fingerprint(short) == "L D W2"
     fence = ["v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]"] + ["s_nop 15"] * 4 + ["ds_read_b128 v[0:3], v20"]
     assert L.check_mfma_c_hazard("k", mk(fence)) == []

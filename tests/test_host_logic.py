@@ -517,11 +517,15 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     calls = {"n": 0}
 
     class FakeChild:                                         # first launch: the port was taken meanwhile -> one retry on a fresh port
-        def __init__(self, cmd, env=None, stderr=None, text=None):
+        def __init__(self, cmd, env=None, stderr=None):
             calls["n"] += 1
             calls["cmd"], calls["env"] = cmd, env
-            calls.setdefault("ports", []).append(cmd[cmd.index("--master-port") + 1])
-            self.stderr = iter(["RuntimeError: ... EADDRINUSE: address already in use\n"] if calls["n"] == 1 else ["rank 0 failed\n"])
+            port = cmd[cmd.index("--master-port") + 1]
+            calls.setdefault("ports", []).append(port)
+            first = ("RuntimeError: The server socket has failed to listen on any local network address. port: %s, useIpv6: false, code: -98, "
+                     "name: EADDRINUSE, message: address already in use\n" % port).encode()
+            # the relay takes BYTES (an undecodable byte must not end it); a later socket error that is not the store's bind is not retried
+            self.stderr = iter([first] if calls["n"] == 1 else [b"\xff\xfe rank 0 failed: some other socket: address already in use\n"])
 
         def wait(self):
             return 1 if calls["n"] == 1 else 7
