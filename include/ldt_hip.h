@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDT_ABI_VERSION 21
+#define LDT_ABI_VERSION 22
 #define LDT_OK 0
 #define LDT_EARG (-1)    /* null / inconsistent argument */
 #define LDT_ESHAPE (-2)  /* unsupported shape */
@@ -99,6 +99,10 @@ int ldt_layernorm_modulate(const float* x, int64_t ldx, uint16_t* y, int64_t ldy
 int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride,
                       const uint16_t* K, int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride,
                       uint16_t* O, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim, void* stream);
+/* Which kernel ldt_attention_fwd runs for a problem of this shape (a query, not a launch; the return value is the route, not a status):
+ * 0 = streaming (attn_fwd_kernel<head_dim>), 1 = resident (attn_fwd_resident_kernel<head_dim>), 2 = whole-head
+ * (attn_fwd_head_kernel<64, ceil(Nk / 64)>).  bench.py uses it to name the rocprofv3 symbol of the kernel it timed. */
+int ldt_attention_route(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim);
 /* Attention + output projection + gated residual in one kernel, for narrow blocks (the Compressor: Dh = 32,
  * C = H*Dh in {64, 128}; model/layers.py:183-200 then :218 / :225):
  *     X[b] += gate[b] * (Wo . O'[b] + bo),   O' = softmax(Q K^T / sqrt(Dh)) V written as [H][Nq][Dh] and re-read as
@@ -325,11 +329,16 @@ typedef struct ldt_score_plan {
     /* Cap on the persistent GEMM grids of this plan (0 = one workgroup per CU = 256).  Two sub-batches sampled on two
        streams give each plan 128: their kernels then share the chip CU-wise and one stream's HBM-bound epilogues /
        attention overlap the other's MFMA-bound main loops (ldt_amd/diffusion.py, `streams`). */
-    int32_t gemm_wgs; int32_t _pad1;
+    int32_t gemm_wgs;
+    /* ldt_sample_loop only: with fold_monitor set, the steps i with i % fold_monitor_every == 0 and the last step run the monitored
+       forward, the others the plain one (0 = every step).  47 monitor launches of ~5 us per monitored forward: every 50th step costs
+       0.05 % of a call and the running maximum covers the whole trajectory, not its two ends. */
+    int32_t fold_monitor_every;
     /* Optional LN-folding monitor (NULL = off): one device float, raised (atomic max; zero it first) after every folded
        residual GEMM of a forward to max over rows of mean^2 / variance of that GEMM's output — the quantity that scales
        the folded projections' rounding error, (1 + mean^2 / variance) x the LayerNorm kernel's.  The sampler sets it on a
-       probe forward before and after the loop (ldt_amd/diffusion.py) and leaves it NULL inside the loop. */
+       probe forward before the loop and, since round 6, inside the loop every fold_monitor_every steps (ldt_amd/diffusion.py),
+       and reads the running maximum once when the loop has ended. */
     float* fold_monitor;
 } ldt_score_plan;
 

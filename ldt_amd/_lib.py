@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDT_HIP_LIB", os.path.join(_HERE, "libldt_hip.so"))   # override: debug builds only
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_BLOCKS = 64
 
 EPI_F32, EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_RESID_F32 = range(5)
@@ -38,7 +38,7 @@ class ScorePlan(C.Structure):
         + [("w_q", _vp * MAX_BLOCKS), ("b_q", _vp * MAX_BLOCKS), ("kv_cond", _vp * MAX_BLOCKS), ("cond_tokens", _i32), ("_pad0", _i32)]
         + [("mod", _vp), ("mod_step_stride", _i64), ("mod_sample_stride", _i64)]
         + [(n, _vp) for n in ("xin", "X", "Hb", "QKV", "Ob", "U")]
-        + [("fold", _vp), ("fold_step_stride", _i64), ("stats", _vp), ("gemm_wgs", _i32), ("_pad1", _i32), ("fold_monitor", _vp)]
+        + [("fold", _vp), ("fold_step_stride", _i64), ("stats", _vp), ("gemm_wgs", _i32), ("fold_monitor_every", _i32), ("fold_monitor", _vp)]
     )
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "ldt_score_lnfold_route": [_i32, _i32, _i32, _i32],
     "ldt_layernorm_modulate": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
     "ldt_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ldt_attention_route": [_i32, _i32, _i32, _i32, _i32],
     "ldt_attention_oproj_resid": [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     "ldt_sgemm": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ldt_sinusoid": [_vp, _vp, _vp, _i32, _i32, _vp],

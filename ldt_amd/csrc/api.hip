@@ -99,6 +99,7 @@ extern "C" int ldt_attention_fwd(const uint16_t* Q, int64_t ldq, int64_t q_batch
                1.4426950408889634f / sqrtf((float)head_dim), nullptr, nullptr, nullptr, 0, nullptr, 0};
     return ldt_attn_launch(&a, head_dim, ST(stream));
 }
+extern "C" int ldt_attention_route(int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim) { return ldt_attn_route(B, H, Nq, Nk, head_dim); }
 extern "C" int ldt_attention_oproj_resid(const uint16_t* Q, int64_t ldq, int64_t q_batch_stride, const uint16_t* K,
                                          int64_t ldk, const uint16_t* V, int64_t ldv, int64_t kv_batch_stride,
                                          int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t head_dim,
@@ -467,9 +468,16 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     hipStream_t s = ST(stream);
     hipError_t e = hipMemsetAsync(step_counter, 0, sizeof(int), s);
     if (e != hipSuccess) { ldt_set_error("sample_loop: memset: %s", hipGetErrorString(e)); return (int)e; }
+    // LN-fold monitor inside the loop (plan->fold_monitor, every plan->fold_monitor_every steps and on the last one): the other steps run a
+    // copy of the plan without it
+    ldt_score_plan plain = *p;
+    plain.fold_monitor = nullptr;
+    const bool mon = p->fold_monitor != nullptr;
+    const int every = p->fold_monitor_every > 0 ? p->fold_monitor_every : 1;
+    auto monitored = [&](int i) { return mon && (i % every == 0 || i == n_steps - 1); };
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i)
-            TRY(enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, s));
+            TRY(enqueue_step(monitored(i) ? p : &plain, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, s));
         return LDT_OK;
     }
     // One step captured, replayed n_steps times; every step-dependent operand is indexed by *step_counter.
@@ -477,8 +485,8 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
     // cannot be captured), fenced against the caller's stream with events on both sides.
     hipStream_t gs = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr, graph_m = nullptr;
+    hipGraphExec_t exec = nullptr, exec_m = nullptr;                     // the plain step and (fold monitor on) the monitored step
     int status = LDT_OK;
 #define HIPTRY(call, what)                                                                   \
     do {                                                                                     \
@@ -496,16 +504,19 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
         HIPTRY(hipStreamWaitEvent(gs, ev_in, 0), "stream wait");
     }
     if (status == LDT_OK) {
-        HIPTRY(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal), "begin capture");
-        if (status == LDT_OK) {
-            const int rc = enqueue_step(p, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, gs);
-            const hipError_t ee = hipStreamEndCapture(gs, &graph);
-            if (rc != LDT_OK) status = rc;
-            else if (ee != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(ee)); status = (int)ee; }
+        for (int pass = 0; pass < (mon ? 2 : 1) && status == LDT_OK; ++pass) {      // pass 0: the plain step; pass 1: the monitored one
+            HIPTRY(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal), "begin capture");
+            if (status == LDT_OK) {
+                const int rc = enqueue_step(pass ? p : &plain, x, x_mean, eps_tmp, coef, mode, noise, noise_step_stride, elem_offset, seed, step_counter, cond, x_traj, gs);
+                const hipError_t ee = hipStreamEndCapture(gs, pass ? &graph_m : &graph);
+                if (rc != LDT_OK) status = rc;
+                else if (ee != hipSuccess) { ldt_set_error("sample_loop: end capture: %s", hipGetErrorString(ee)); status = (int)ee; }
+            }
         }
     }
     if (status == LDT_OK) HIPTRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "graph instantiate");
-    for (int i = 0; i < n_steps && status == LDT_OK; ++i) HIPTRY(hipGraphLaunch(exec, gs), "graph launch");
+    if (status == LDT_OK && mon) HIPTRY(hipGraphInstantiate(&exec_m, graph_m, nullptr, nullptr, 0), "graph instantiate");
+    for (int i = 0; i < n_steps && status == LDT_OK; ++i) HIPTRY(hipGraphLaunch(monitored(i) ? exec_m : exec, gs), "graph launch");
     if (gs) {
         if (status == LDT_OK) {
             HIPTRY(hipEventRecord(ev_out, gs), "event record");
@@ -514,7 +525,9 @@ extern "C" int ldt_sample_loop(const ldt_score_plan* p, float* x, float* x_mean,
         (void)hipStreamSynchronize(gs);          // the exec must outlive its in-flight launches
     }
     if (exec) (void)hipGraphExecDestroy(exec);
+    if (exec_m) (void)hipGraphExecDestroy(exec_m);
     if (graph) (void)hipGraphDestroy(graph);
+    if (graph_m) (void)hipGraphDestroy(graph_m);
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_out) (void)hipEventDestroy(ev_out);
     if (gs) (void)hipStreamDestroy(gs);

@@ -30,6 +30,9 @@
 #ifndef ATT_STREAM32_KT
 #define ATT_STREAM32_KT 128              /* tools/dbg A/B: 64 = the round-5 form (attn_block chain) */
 #endif
+#ifndef ATT_ABL
+#define ATT_ABL 0                        /* tools/dbg timing-only builds of attn_fwd_kernel (wrong results): bit 1 no K / V fetch behind tile 0, 2 no tile compute, 4 no output store */
+#endif
 template <int DH, bool OPROJ = false>
 __global__ __launch_bounds__(256, (DH == 32 && ATT_STREAM32_KT == 128) ? 3 : 4) void attn_fwd_kernel(const AttnArgs a) {   // (four score accumulators: 168 VGPRs)
     constexpr int KT = (DH == 32) ? ATT_STREAM32_KT : 64;   // keys per LDS tile
@@ -121,22 +124,26 @@ __global__ __launch_bounds__(256, (DH == 32 && ATT_STREAM32_KT == 128) ? 3 : 4) 
         const bool more = t + 1 < ntiles;
         char* cur = smem + BUF * 2 * TILE;
         char* nxt = smem + (BUF ^ 1) * 2 * TILE;
-        if (more) stage_load(Kb, a.ldk, gk_off, kv0 + KT);
-        if constexpr (KT == 128) {
+        const bool fetch = more && !(ATT_ABL & 1);             // (ATT_ABL: tools/dbg timing-only builds; 0 in the product)
+        if (fetch) stage_load(Kb, a.ldk, gk_off, kv0 + KT);
+        if constexpr ((ATT_ABL & 2) != 0) {                    // timing-only: the tile's traffic without its compute
+            if (fetch) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+            asm volatile("" : "+v"(oacc[0]));
+        } else if constexpr (KT == 128) {
             const bool two = kv0 + 64 < a.Nk;                // (uniform) keys 64.. of the tile exist
             f32x16 sa0, sa1, sb0, sb1;
             attn_scores<DH>(cur, qf, sa0, sa1, lo);
             if (two) attn_scores<DH>(cur + 64 * ROWB, qf, sb0, sb1, lo);
             __builtin_amdgcn_sched_barrier(0);
             attn_softmax_pv<DH>(cur + TILE, sa0, sa1, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
-            if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+            if (fetch) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
             if (two) attn_softmax_pv<DH>(cur + TILE + 64 * ROWB, sb0, sb1, oacc, m_run, l_run, kv0 + 64, a.Nk, hh, c, lo);
         } else {
             attn_block<DH>(cur, cur + TILE, 0, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
-            if (more) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
+            if (fetch) { stage_store(nxt, sk_off); stage_load(Vb, a.ldv, gv_off, kv0 + KT); }
             attn_block<DH>(cur, cur + TILE, 1, qf, oacc, m_run, l_run, kv0, a.Nk, hh, c, lo);
         }
-        if (more) stage_store(nxt + TILE, sv_off);
+        if (fetch) stage_store(nxt + TILE, sv_off);
         __syncthreads();
     };
     for (int t = 0; t < ntiles; t += 2) {
@@ -231,7 +238,11 @@ __global__ __launch_bounds__(256, (DH == 32 && ATT_STREAM32_KT == 128) ? 3 : 4) 
     for (int it = 0; it < (32 * LPR) / 64; ++it) {
         const int row = it * (64 / LPR) + lane / LPR, ch = lane % LPR;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(ost + row * ORS + ch * 16);
+#if ATT_ABL & 4
+        if (q0 + row < a.Nq && v[0] == (bf16_t)12345.0f) *reinterpret_cast<bf16x8*>(ob + (long)row * DH + ch * 8) = v;
+#else
         if (q0 + row < a.Nq) *reinterpret_cast<bf16x8*>(ob + (long)row * DH + ch * 8) = v;
+#endif
     }
 }
 
@@ -694,6 +705,20 @@ int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s) {
     return ldt_check_launch("attn_oproj");
 }
 
+// Which kernel ldt_attn_launch takes for a problem: 0 = streaming (attn_fwd_kernel), 1 = resident (attn_fwd_resident_kernel), 2 = whole-head
+// (attn_fwd_head_kernel<64, ceil(Nk / 64)>).  Also exported (ldt_attention_route) so that bench.py names the symbol it timed instead of guessing.
+int ldt_attn_route(int B, int H, int Nq, int Nk, int dh) {
+    // Short sequences (one 128-row query block, keys/values of a head fit 64 KiB of LDS): resident kernel — K/V
+    // loaded once, no per-tile barrier (measured 9.0 vs 9.7 us at T=32).  Longer query sets run the streaming
+    // kernel, which spreads (b,h,q-block) over more workgroups (35 vs 37 us at T=256, 46 vs 56 us at 2048x256).
+    static const int force = getenv("LDT_ATTN_FORCE") ? atoi(getenv("LDT_ATTN_FORCE")) : 0;   // 1 stream, 2 resident, 3 whole-head (tools/dbg)
+    const bool fits = (long)Nk * dh <= 256 * 64;
+    if (fits && (force == 2 || (force == 0 && Nq <= 128))) return 1;
+    // 129..256 queries of a Dh = 64 head (the Score at T = 256): the whole-head 8-wave kernel
+    if (fits && dh == 64 && Nq <= 256 && (long)B * H < (1L << 31) && (force == 3 || (force == 0 && Nq > 128))) return 2;
+    return 0;
+}
+
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s) {
     LDT_REQUIRE(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, LDT_ESHAPE, "attention: empty problem B=%d H=%d Nq=%d Nk=%d", a->B, a->H, a->Nq, a->Nk);
     LDT_REQUIRE(dh == 32 || dh == 64, LDT_ESHAPE, "attention: head dim %d not built (32, 64)", dh);
@@ -701,14 +726,9 @@ int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s) {
                 ldt_aligned16(a->Q) && ldt_aligned16(a->K) && ldt_aligned16(a->V) && ldt_aligned16(a->O), LDT_EALIGN,
                 "attention: Q/K/V rows must be 16-byte aligned");
     LDT_REQUIRE(a->H <= 65535 && a->B <= 65535, LDT_ESHAPE, "attention: grid too large");
-    // Short sequences (one 128-row query block, keys/values of a head fit 64 KiB of LDS): resident kernel — K/V
-    // loaded once, no per-tile barrier (measured 9.0 vs 9.7 us at T=32).  Longer query sets run the streaming
-    // kernel, which spreads (b,h,q-block) over more workgroups (35 vs 37 us at T=256, 46 vs 56 us at 2048x256).
-    static const int force = getenv("LDT_ATTN_FORCE") ? atoi(getenv("LDT_ATTN_FORCE")) : 0;   // 1 stream, 2 resident (tools/dbg)
-    const bool fits = (long)a->Nk * dh <= 256 * 64;
-    if (fits && (force == 2 || (force == 0 && a->Nq <= 128))) return dh == 64 ? launch_resident<64>(a, s) : launch_resident<32>(a, s);
-    // 129..256 queries of a Dh = 64 head (the Score at T = 256): the whole-head 8-wave kernel
-    if (fits && dh == 64 && a->Nq <= 256 && (long)a->B * a->H < (1L << 31) && (force == 3 || (force == 0 && a->Nq > 128))) return launch_head<64>(a, s);
+    const int route = ldt_attn_route(a->B, a->H, a->Nq, a->Nk, dh);
+    if (route == 1) return dh == 64 ? launch_resident<64>(a, s) : launch_resident<32>(a, s);
+    if (route == 2) return launch_head<64>(a, s);
     const long nqb = (a->Nq + 127) / 128, groups = ((long)a->B * a->H + 7) / 8;
     LDT_REQUIRE(groups * 8 * nqb < (1L << 31), LDT_ESHAPE, "attention: grid too large");
     dim3 grid((unsigned)(groups * 8 * nqb)), block(256);

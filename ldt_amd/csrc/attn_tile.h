@@ -34,6 +34,9 @@ struct AttnLaneOffs {
 //     branch is rarely taken, which removes the per-block alpha / rescale work (16 v_pk_mul at Dh = 64).
 //   * VALU-lean: packed fp32 FMA/ADD (two scores per instruction), max3 row maxima, masking code only on ragged tiles.
 #define ATT_THR 6.0f
+#ifndef ATT_SCALAR_SOFTMAX
+#define ATT_SCALAR_SOFTMAX 0
+#endif
 template <int DH>
 __device__ __forceinline__ void attn_block(const char* Kt, const char* Vt, const int kt, const bf16x8 (&qf)[DH / 16], f32x16 (&oacc)[DH / 32],
                                            float& m_run, float& l_run, int kv0, int Nk, int hh, float c,
@@ -163,6 +166,23 @@ __device__ __forceinline__ void attn_softmax_pv(const char* Vt, f32x16& s0, f32x
             }
     }
     bf16x8 pf[4];
+#if ATT_SCALAR_SOFTMAX                                               /* tools/dbg A/B: scalar v_fma / v_add instead of the packed forms */
+    const float nmc = -m_run * c;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        float ea0 = __builtin_fmaf(s0[i], c, nmc), ea1 = __builtin_fmaf(s0[i + 1], c, nmc);
+        float eb0 = __builtin_fmaf(s1[i], c, nmc), eb1 = __builtin_fmaf(s1[i + 1], c, nmc);
+        asm volatile("" : "+v"(ea0), "+v"(ea1), "+v"(eb0), "+v"(eb1));   // (keeps hipcc's SLP pass from re-packing the four)
+        const float pa0 = __builtin_amdgcn_exp2f(ea0), pa1 = __builtin_amdgcn_exp2f(ea1);
+        const float pb0 = __builtin_amdgcn_exp2f(eb0), pb1 = __builtin_amdgcn_exp2f(eb1);
+        q0 += pa0; q1 += pa1; q2 += pb0; q3 += pb1;
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        pf[i >> 3][i & 7] = (bf16_t)pa0;       pf[i >> 3][(i & 7) + 1] = (bf16_t)pa1;
+        pf[2 + (i >> 3)][i & 7] = (bf16_t)pb0; pf[2 + (i >> 3)][(i & 7) + 1] = (bf16_t)pb1;
+    }
+    l_run += (q0 + q1) + (q2 + q3);
+#else
     const f32x2 c2 = {c, c}, nmc2 = {-m_run * c, -m_run * c};
     f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
 #pragma unroll
@@ -177,6 +197,7 @@ __device__ __forceinline__ void attn_softmax_pv(const char* Vt, f32x16& s0, f32x
         pf[2 + (i >> 3)][i & 7] = (bf16_t)pb[0]; pf[2 + (i >> 3)][(i & 7) + 1] = (bf16_t)pb[1];
     }
     l_run += (psa[0] + psa[1]) + (psb[0] + psb[1]);
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2)                                   // 16-key slices: block s2 >> 1, half s2 & 1
 #pragma unroll

@@ -1349,6 +1349,10 @@ bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs) {
     const int lim = (max_wgs > 0 && max_wgs < LDT_NUM_CUS) ? max_wgs : LDT_NUM_CUS;
     auto small = [&](int N) { return (long)((M + 255) / 256) * ((N + 255) / 256) * 8 < (long)lim * 5; };
     if (!(gemm_variant_env() == 0 && M % 128 == 0 && D % 64 == 0 && F % 64 == 0 && D <= 1024 && small(D) && small(3 * D) && small(F))) return false;
+    // the folded residual producers run 64 x 128 tiles (statistics per 32 columns need whole 128-column slabs): below 5/8 of the workgroups
+    // they leave the chip half empty and the LayerNorm launches they replace are cheaper — M = 1024 (B = 32 x 32 tokens): folded 1.788 ms per
+    // SDE step against 1.670 with the 64 x 64 plain forms + LayerNorm kernels (profiles/r06_c5_ln_fold_decision.txt); M = 2048: 256 tiles, folded wins
+    if ((long)(M / 64) * (D / 128) * 8 < (long)lim * 5) return false;
     return ldt_gemm_mid_lnfold_takes(EPI_RESID_F32, M, D, D) && ldt_gemm_mid_lnfold_takes(EPI_RESID_F32, M, D, F) &&
            ldt_gemm_mid_lnfold_takes(EPI_BF16, M, 3 * D, D) && ldt_gemm_mid_lnfold_takes(EPI_GELU_BF16, M, F, D);
 }

@@ -89,6 +89,7 @@ bool ldt_gemm_lnfold_v1_route(int M, int D, int F, int max_wgs);   // small batc
 int ldt_gemm_lnfold_launch(int epi, const GemmArgs* a, hipStream_t stream);   // producer (RESID + xs/stats) or consumer (stats_in)
 int ldt_ln_launch(const LnArgs* a, hipStream_t s);
 int ldt_attn_launch(const AttnArgs* a, int dh, hipStream_t s);
+int ldt_attn_route(int B, int H, int Nq, int Nk, int dh);       // 0 streaming, 1 resident, 2 whole-head (attention.hip)
 int ldt_attn_oproj_launch(const AttnArgs* a, int dh, hipStream_t s);
 int ldt_cast_pad_launch(const float* src, long lds, bf16_t* dst, long ldd, long rows, int cols, int cols_pad, hipStream_t s);
 int ldt_sampler_step_launch(const StepArgs* a, hipStream_t s);

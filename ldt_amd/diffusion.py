@@ -212,6 +212,7 @@ class DiffusionBase:
             bounds = [B * i // streams for i in range(streams + 1)]
             jobs, keep = [], []
             fold = None
+            fold_mon = None                                                           # running max of mean^2 / variance over the monitored steps
             for i in range(streams):
                 lo, hi = bounds[i], bounds[i + 1]
                 Bs = hi - lo
@@ -228,7 +229,14 @@ class DiffusionBase:
                         # guard: a monitored forward on the first sub-batch at step 0 (0.1 % of a 1000-step call); rows whose
                         # mean dwarfs their spread switch this model to the LayerNorm kernels (Score.fold_probe)
                         model.fold_probe(xs, 0, mod, fold)
-                    plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if model.can_fold(Bs, T, wgs) else None, slot=i, gemm_wgs=wgs)
+                    folding = model.can_fold(Bs, T, wgs)                              # (the probe may just have switched it off)
+                    if folding and fold_mon is None:
+                        fold_mon = torch.zeros(1, dtype=torch.float32, device=dev)
+                    # inside the loop the same monitor runs every LDT_FOLD_MONITOR_EVERY steps (default 50: 47 launches of ~5 us per monitored
+                    # step = 0.05 % of a call) and on the last step; the running maximum is read once after the loop (round 6: a trajectory
+                    # that passes the bound mid-way is seen, not just its two ends)
+                    plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if folding else None, slot=i, gemm_wgs=wgs,
+                                      monitor=fold_mon if folding else None, monitor_every=int(os.environ.get("LDT_FOLD_MONITOR_EVERY", "50")))
                 else:
                     c_buf = torch.empty((Bs, model.t_dim), dtype=torch.float32, device=dev)
                     modb = torch.empty((Bs, model.n_mod), dtype=torch.float32, device=dev)
@@ -281,8 +289,8 @@ class DiffusionBase:
                 main.synchronize()                                                    # scratch / sub-streams must outlive the loop
             if trajectory is not None:
                 trajectory.append(torch.cat([j[-1] for j in jobs], 1))
-            if fold is not None and model.can_fold(bounds[1], T, 0 if streams == 1 else max(256 // streams, 1)):
-                model.fold_probe(x[:bounds[1]], N - 1, mod, fold)                     # and on the finished latents (affects later calls)
+            if fold_mon is not None:
+                model.defer_fold_ratio(fold_mon)                                      # read (a device sync) at the next can_fold(): affects later calls
             return x_mean if denoise else x
         # ---- generic loop: any score_fn, correctors, trajectory dumps; every update is still one HIP kernel ----
         ts_d = ts.to(dev)

@@ -79,6 +79,7 @@ class Score(nn.Module):
         self._cond_cache = {}
         self._fold_disabled = False      # set by fold_probe when a row's mean^2 / variance exceeds FOLD_MAX_MEAN_RATIO
         self.fold_ratio_seen = 0.0       # largest mean^2 / variance the probes have measured (diagnostic)
+        self._fold_pending = None        # device scalar the last sampling loop's in-loop monitor wrote; read by collect_fold_ratio()
 
     # ------------------------------------------------------------------ packed weights
     @property
@@ -232,7 +233,8 @@ class Score(nn.Module):
             }
         return self._ws[k]
 
-    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0, monitor=None):
+    def plan(self, B, T, mod, mod_step_stride, mod_sample_stride, kv_cond=None, cond_tokens=0, fold=None, slot=0, gemm_wgs=0, monitor=None,
+             monitor_every=0):
         """ctypes `ldt_score_plan` for a (B,T) batch reading AdaLN rows from `mod`; kv_cond: {block: K|V rows};
         fold: the `fold_table(mod)` of a batch-shared `mod` (enables the LN-folded GEMM epilogues); slot / gemm_wgs: workspace
         set and persistent-grid cap of a sub-batch that shares the GPU with another stream (diffusion.py, `streams`)."""
@@ -262,6 +264,7 @@ class Score(nn.Module):
             p.fold, p.fold_step_stride, p.stats = fold.data_ptr(), fold.stride(0), W["stats"].data_ptr()
             if monitor is not None:
                 p.fold_monitor = monitor.data_ptr()
+                p.fold_monitor_every = int(monitor_every)               # ldt_sample_loop: monitored steps (0 = every step)
         p._keep = (P, W, mod, kv_cond, fold, monitor)   # keep the buffers alive as long as the plan
         return p
 
@@ -301,6 +304,7 @@ class Score(nn.Module):
         there the loader waves form the row statistics while the ring fills (98.5 -> 92.5 us per block, profiles/r04_t32_kernel_sequence*.txt).
         The C++ forward makes the same decision (`ldt_score_lnfold_route`); this method asks it.
         LDT_LN_FOLD=0 disables folding, =2 forces it wherever a route exists; LDT_LN_FOLD_SMALL=0 disables (b) only (A/B runs)."""
+        self.collect_fold_ratio()
         mode = int(os.environ.get("LDT_LN_FOLD", "1"))
         D, M = self.hidden_size, B * T
         F = self.Transformer[0].mlp.out.in_channels if not self.unet else 0
@@ -331,7 +335,11 @@ class Score(nn.Module):
         out = torch.empty_like(x)
         check(lib().ldt_score_forward(ctypes.byref(plan), x.contiguous().data_ptr(), out.data_ptr(), step.data_ptr(), ops.stream_ptr()),
               "ldt_score_forward")
-        ratio = float(mon.item())
+        return self.note_fold_ratio(float(mon.item()))
+
+    def note_fold_ratio(self, ratio):
+        """Record a measured max mean^2 / variance of the folded LayerNorm inputs (a probe forward, or the running maximum the sampling
+        loop's in-loop monitor wrote) and switch this model to the LayerNorm kernels when it exceeds FOLD_MAX_MEAN_RATIO."""
         self.fold_ratio_seen = max(self.fold_ratio_seen, ratio)
         if ratio > self.FOLD_MAX_MEAN_RATIO and not self._fold_disabled:
             import warnings
@@ -340,6 +348,21 @@ class Score(nn.Module):
                           "would lose accuracy there; using the LayerNorm kernels from now on (LDT_LN_FOLD=2 forces folding)"
                           % (ratio, self.FOLD_MAX_MEAN_RATIO))
         return ratio
+
+    def defer_fold_ratio(self, monitor):
+        """The sampling loop hands over the device scalar its in-loop monitor accumulates into INSTEAD of reading it: a read is a device
+        synchronisation, and at the end of `sample()` it would serialise the next call's host work (the CPU draw of x0: 100-150 ms for a
+        512-shape global batch, tools/dbg/x0_draw_cost.py) behind the ~0.1 s of steps still queued on the GPU.  The value is collected at the
+        next decision that depends on it (can_fold) — i.e. after the next call's x0 has been drawn."""
+        self.collect_fold_ratio()
+        self._fold_pending = monitor
+
+    def collect_fold_ratio(self):
+        """Read (synchronising) the pending in-loop monitor value, if any; -> the largest ratio seen so far."""
+        if self._fold_pending is not None:
+            mon, self._fold_pending = self._fold_pending, None
+            self.note_fold_ratio(float(mon.item()))
+        return self.fold_ratio_seen
 
     def fold_table(self, mod):
         """Per-step S / C vectors of the LN-folded projections (include/ldt_hip.h, ldt_gemm_resid_lnstats), fp32

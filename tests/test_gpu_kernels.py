@@ -553,7 +553,7 @@ def test_gemm256_variants_bit_equal(tmp_path):
     before it lands).  Same seeded problems in two child processes: plain RESID_F32 and the LN-fold producer (M = 16,384 x N = 1,024: exactly
     256 tiles), the LN-fold consumer with GELU on a multi-tile persistent shape (N = 4,096: four tiles per workgroup) and a plain bf16
     projection (N = 3,072), each launched three times (run-to-run differences would betray a race).  (Round 3 also held the round-2 operand
-    stream, removed in round 4, to the same bits.)"""
+    stream, removed in round 4, to the same bits; round 6 holds the W-from-registers form of the one-tile kernels to them.)"""
     import os
     import subprocess
     import sys
@@ -588,14 +588,16 @@ for rep in range(3):
 torch.save(outs, sys.argv[1])
 ''' % ROOT
     res = {}
-    for ring in ("0", "1"):
-        out = tmp_path / ("ring%s.pt" % ring)
-        env = dict(os.environ, LDT_RESID_RING=ring)
+    # third child (round 6): the one-tile residual GEMMs with the weight operand loaded straight into registers from a fragment-order copy
+    # (gemm_bf16.hip WREG: asm loads, hand-counted waits, no W in LDS; LDT_GEMM_WREG=1 packs the copy on the fly) — same MFMA order, same bits
+    for ring, wreg in (("0", "0"), ("1", "0"), ("1", "1")):
+        out = tmp_path / ("ring%s_wreg%s.pt" % (ring, wreg))
+        env = dict(os.environ, LDT_RESID_RING=ring, LDT_GEMM_WREG=wreg)
         r = subprocess.run([sys.executable, "-c", child, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[ring] = torch.load(out)
-    base = res["0"]
+        res[(ring, wreg)] = torch.load(out)
+    base = res[("0", "0")]
     for key, cur in res.items():
         for k in base:
-            assert torch.equal(cur[k], base[k]), "LDT_RESID_RING=%s differs from the register-epilogue path in %s" % (key, k)
+            assert torch.equal(cur[k], base[k]), "LDT_RESID_RING=%s LDT_GEMM_WREG=%s differs from the register-epilogue path in %s" % (key + (k,))
     assert bool(torch.isfinite(base["x1"]).all()) and float(base["x1"].abs().mean()) > 0.1 and float(base["u"].float().abs().mean()) > 0.01

@@ -450,6 +450,69 @@ def test_lnfold_sampler_vs_oracle_and_unfolded(monkeypatch):
     assert rel_mse(folded.cpu(), plain.cpu()) < TOL_LATENT
 
 
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_fold_monitor_inside_the_loop_sees_a_mid_trajectory_offset(monkeypatch, use_graph):
+    """The LN-fold guard watches the WHOLE trajectory (round 6): `ldt_sample_loop` runs the monitored forward every
+    LDT_FOLD_MONITOR_EVERY steps and on the last one, `sample_discrete` reads the running maximum of mean^2 / variance once after the
+    loop.  A common offset over the hidden channels appears half-way through the steps (from step N/2 on the AdaLN table holds a gate
+    of 1e4 for block 0's attention branch, whose output bias is 1 on every channel: every row of the residual stream gains the same
+    constant): step 0 and a clean trajectory stay far below the bound; this one trips it, the model switches to the LayerNorm kernels,
+    and the NEXT call runs exactly the LDT_LN_FOLD=0 path.  Both the plain loop and the two-graph replay (monitored / plain step graphs)."""
+    import warnings
+    import ldt_amd
+    from oracle import ldt_oracle as O
+    N = 25
+    cfg = ldt_amd.airplane_config(latent_tokens=32, sample_N=N, **{
+        "score.hidden_size": 256, "score.num_heads": 4, "score.num_blocks": 3, "score.t_dim": 128,
+        "compressor.max_outputs": 256, "compressor.outsize": 256, "data.tr_max_sample_points": 256})
+    torch.manual_seed(11)
+    score = ldt_amd.Score(cfg.score)
+    comp = ldt_amd.Compressor(cfg.compressor)
+    tr = ldt_amd.Trainer(cfg, score, comp, "cuda:0")
+    B, T, z = 8, cfg.score.z_scale, cfg.score.z_dim
+    x0, noises = O.draw_noises(77, B, T, z, N)
+    noise = torch.stack(noises)
+    kw = dict(score_fn=tr.score_fn, num_samples=B, N=N, predictor="ancestral", corrector=None, corrector_steps=1, shape=(T, z),
+              time_eps=cfg.sde.sample_time_eps, probability_flow=False, denoise=True, snr=0.01, device="cuda:0", x0=x0, streams=1,
+              use_graph=use_graph)
+    monkeypatch.setenv("LDT_FOLD_MONITOR_EVERY", "5")
+    monkeypatch.setenv("LDT_LN_FOLD", "2")                    # (this small shape folds only when forced; the guard still records and switches)
+    assert tr.model.can_fold(B, T)
+    D = cfg.score.hidden_size
+    with torch.no_grad():
+        score.Transformer[0].fc_o.bias.fill_(1.0)             # (in place through the parameter: version bump -> repack)
+        score.Transformer[0].fc_o.weight.zero_()              # block 0's attention branch = the constant 1 on every channel, times its gate
+    clean = tr.SDE.sample_discrete(**kw, noise=noise)         # (the seeded gates are small and of either sign: no common offset)
+    assert tr.model._fold_pending is not None                 # the loop left its running maximum on the device: no sync at the end of a call
+    assert 0.0 < tr.model.collect_fold_ratio() < tr.model.FOLD_MAX_MEAN_RATIO and not tr.model._fold_disabled
+    # from step N/2 on, block 0's attention gate is 1e4 on every channel; its branch is the constant 1 (fc_o.weight = 0, bias = 1): x gains a
+    # common offset of 1e4 there (x += gate * 1) against a spread of O(10) (random-weight latents grow along the trajectory), i.e. mean^2 /
+    # variance ~ 10^5 on every later LayerNorm input; steps 0 .. N/2 - 1 are untouched
+    time_table = tr.model.time_table
+
+    def late_gate(t, *a, **k):
+        c, mod = time_table(t, *a, **k)
+        if mod.shape[0] == N:
+            mod[N // 2:, 2 * D:3 * D] = 1.0e4                 # block 0: shift_msa | scale_msa | gate_msa | ...
+        return c, mod
+    monkeypatch.setattr(tr.model, "time_table", late_gate)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr.SDE.sample_discrete(**kw, noise=noise)
+        tr.model.collect_fold_ratio()                         # (what the next call's can_fold() does first)
+    monkeypatch.setattr(tr.model, "time_table", time_table)
+    assert tr.model._fold_disabled and tr.model.fold_ratio_seen > tr.model.FOLD_MAX_MEAN_RATIO
+    assert any("LayerNorm kernels from now on" in str(x.message) for x in w)
+    monkeypatch.delenv("LDT_LN_FOLD")
+    assert not tr.model.can_fold(B, T)                        # the next call takes the fallback path ...
+    after = tr.SDE.sample_discrete(**kw, noise=noise)
+    monkeypatch.setenv("LDT_LN_FOLD", "0")
+    tr.model._fold_disabled = False
+    plain = tr.SDE.sample_discrete(**kw, noise=noise)
+    assert torch.equal(after, plain)                          # ... which is the LayerNorm-kernel loop, bit for bit
+    assert rel_mse(clean.cpu(), plain.cpu()) < TOL_LATENT
+
+
 def test_substreams_equal_single_stream(env, monkeypatch):
     """Sub-batches sampled on two concurrent HIP streams (two host threads, each with its own plan, workspace and step
     counter) give the same latents as one stream — injected noise and device Philox noise (keyed by global element index),
