@@ -831,7 +831,7 @@ def main():
         if not args.no_roofline and cond is None:
             roof, roofs, kernels = roofline_pass(trainer, cfg, args.batch_per_gpu)
             log("roofline pass done: %s" % json.dumps(kernels))
-            line["roofline"] = roof
+            line["roofline"] = dict(roof)                # (a copy: the flat `x_` scalars below go into this object only)
             line["roofline_attention"] = roofs.get("attention") or dict(attention_standalone(trainer, cfg, args.batch_per_gpu),
                                                                         fused_into="gemm_qkv: %s" % roofs["gemm_qkv"]["kernel"])
             line["roofline_kernels"] = roofs
