@@ -539,3 +539,26 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     assert calls["n"] == 2                                   # retried once (address in use), not again (an ordinary failure is relayed)
     c5 = bench.parse(["--config", "c5"])
     assert (c5.tokens, c5.batch_per_gpu) == (32, 32) and bench.parse([]).tokens == 256 and bench.parse([]).batch_per_gpu == 64
+
+
+def test_bench_preflight_fails_fast_before_any_model_is_built(monkeypatch):
+    """`bench.py --gpus N` under a launcher checks, before it touches a GPU or builds a model, that the launcher's world is the one asked
+    for and that this node shows a device per local rank: a mis-sized launch dies in seconds with the reason."""
+    import bench
+    for k, v in dict(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999").items():
+        monkeypatch.setenv(k, v)
+    touched = []
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda *a: touched.append(a))
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(AssertionError, match="2 rank\\(s\\) on this node but only 1 visible GPU"):
+        bench.main()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(AssertionError, match="WORLD_SIZE=2, --gpus=4"):
+        bench.main()
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(AssertionError, match="LOCAL_RANK=3 outside"):
+        bench.main()
+    assert not touched                                       # nothing selected a device, nothing was built
