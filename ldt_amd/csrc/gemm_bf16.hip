@@ -1254,15 +1254,18 @@ static bool gemm256_takes(int epi, const GemmArgs* a) {
 
 template <int EPI, int FOLD = FOLD_NONE>
 static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
-    // Tile order: wide outputs (QKV: 12 column tiles, MLP-up: 16) are swept in groups of 8 row panels, so an XCD's 32
-    // workgroups hold an 8 x 4 block of tiles (8 X panels + 4 W panels live in its 4 MiB L2) instead of 2 x 16 — the W panel
-    // set is then re-streamed from the fabric once per 8 row panels, not once per 2 (profiles/: MLP-up fetched 2.5x its
-    // unique bytes in row-major order).  Speed: QKV +1.6 %, others equal (tools/dbg/gm_bench.py).  LDT_GEMM_GM overrides.
+    // Tile order: wide outputs (QKV: 12 column tiles, MLP-up: 16) are swept in groups of row panels, so an XCD's 32 workgroups hold a
+    // block of tiles (round 2-5: 8 x 4 = 8 X panels + 4 W panels in its 4 MiB L2; round 6: 4 x 8) instead of 2 x 16 — the W panel set is
+    // then re-streamed from the fabric once per group of row panels, not once per 2 (profiles/: MLP-up fetched 2.5x its unique bytes in
+    // row-major order).  LDT_GEMM_GM overrides (LDT_QKV_GM: the fused QKV + attention kernel alone).
     static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;
     const int gm_dbg = g_group_m.load();
     GemmArgs a_copy = *a_in;
     const int tn = a_in->N / 256, tm = a_in->M / 256;
-    a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
+    // Round 6: groups of 4 (an XCD's 32 workgroups = 4 row panels x 8 column tiles per round) instead of 8 — re-swept on the whole loop with the
+    // fused QKV + attention kernel and the LN-folded MLP-up in place: 8 / 4 / 1 row panels = 10.76-10.79 / 10.59-10.64 / 10.56-10.60 ms per SDE
+    // step on one box (MLP-up alone -1.1 %, the QKV kernel -0.4 %; tools/dbg/gm_loop_sweep.py, profiles/r06_tile_order_sweep.txt).
+    a_copy.group_m = gm_dbg >= 0 ? gm_dbg : gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 4 : 1;
     // residual rows of a one-tile workgroup through the operand ring (v2_epilogue_staged XRING, kernel <.., .., 1>): needs the exact VMEM op
     // count of the epilogue (no per-sample gate loads, no debug skips) and 16-B aligned rows.  LDT_RESID_RING=0: A/B runs.
     static const bool xring_on = !(getenv("LDT_RESID_RING") && atoi(getenv("LDT_RESID_RING")) == 0);
@@ -1320,8 +1323,8 @@ bool ldt_gemm_qkv_attn256_try(const GemmArgs* a_in, int tokens, int head_dim, bo
     const int lim = (g.max_wgs > 0 && g.max_wgs < LDT_NUM_CUS) ? g.max_wgs : LDT_NUM_CUS;
     if (tiles * 8 < (long)lim * 5) return false;
     GemmArgs a = g;
-    static const int gm_env = getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;
-    a.group_m = gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 8 : 1;
+    static const int gm_env = getenv("LDT_QKV_GM") ? atoi(getenv("LDT_QKV_GM")) : getenv("LDT_GEMM_GM") ? atoi(getenv("LDT_GEMM_GM")) : -1;   // tools/dbg
+    a.group_m = gm_env >= 0 ? gm_env : (tn >= 8 && tm >= 8) ? 4 : 1;     // (4 since round 6: see launch_256)
     const int grid = tiles < lim ? (int)tiles : lim;
     auto launch = [&]() -> int {
         if (folded) {
