@@ -233,7 +233,7 @@ class DiffusionBase:
                     if folding and fold_mon is None:
                         fold_mon = torch.zeros(1, dtype=torch.float32, device=dev)
                     # inside the loop the same monitor runs every LDT_FOLD_MONITOR_EVERY steps (default 50: 47 launches of ~5 us per monitored
-                    # step = 0.05 % of a call) and on the last step; the running maximum is read once after the loop (round 6: a trajectory
+                    # step = 0.05 % of a call) and on the last step; the running maximum is read at the NEXT call's first can_fold() (round 6: a trajectory
                     # that passes the bound mid-way is seen, not just its two ends)
                     plan = model.plan(Bs, T, mod, model.n_mod, 0, fold=fold if folding else None, slot=i, gemm_wgs=wgs,
                                       monitor=fold_mon if folding else None, monitor_every=int(os.environ.get("LDT_FOLD_MONITOR_EVERY", "50")))

@@ -331,7 +331,7 @@ class Score(nn.Module):
         B, T, _ = x.shape
         mon = torch.zeros(1, dtype=torch.float32, device=x.device)
         step = torch.full((1,), int(step_index), dtype=torch.int32, device=x.device)
-        plan = self.plan(B, T, mod, self.n_mod, 0, fold=fold, slot=0, monitor=mon)   # (runs before / after the loop on the same stream: shares its workspace)
+        plan = self.plan(B, T, mod, self.n_mod, 0, fold=fold, slot=0, monitor=mon)   # (runs before the loop on the same stream: shares its workspace)
         out = torch.empty_like(x)
         check(lib().ldt_score_forward(ctypes.byref(plan), x.contiguous().data_ptr(), out.data_ptr(), step.data_ptr(), ops.stream_ptr()),
               "ldt_score_forward")
