@@ -13,11 +13,17 @@ Weights are seeded random-init (no checkpoints reachable), noise is device Philo
     python bench.py --config c5 [--gpus N]           # BASELINE configs[4]: ViPC-conditioned sampling, 32 shapes per GPU, 32 tokens
 
 Rank 0 prints ONE JSON line: metric shapes/sec (whole job) and, at N=1,
-  roofline      dominant kernel of the Score forward, HIP-event timed inside this process (+ every kernel class in
-                `roofline_kernels`, each against the roofline that bounds it; `roofline_attention` = HBM GB/s)
+  roofline      dominant kernel of the Score forward, HIP-event timed inside this process, with ITS OWN PMC traffic / MFMA utilisation
+                (+ every kernel class in `roofline_kernels`, each against the roofline that bounds it; `roofline_attention` = HBM GB/s);
+                also carries every secondary figure of the line as an `x_...` scalar (the driver's record keeps only the scalar members
+                of the contract keys)
   cpu_baseline  config C1 EXACTLY (B=4, T=256, N=100, decode included) on the CPU oracle, x 1/10
-  parity        the same C1 run on the GPU with the same injected noise: per-step rel-MSE curve, final latents, Chamfer
-  extra         BASELINE configs[3] (Compressor B=1024), configs[4]'s per-GPU share (ViPC, B=32, T=32), shipped T=32
+  parity        top level: the FIXED-BAR end-to-end fixture at production width (C1's shape, well-conditioned weights): per-step / final
+                latents, decoded points, Chamfer, pass; `c1_latents`: the C1 run the cpu_baseline times, same injected noise (latents to
+                1e-4); `ill_conditioned_random_weights`: that run's decoded-cloud figures, informational
+  extra         the headline workload on the LayerNorm-kernel path (the LN-fold guard's fallback), BASELINE configs[3] (Compressor
+                B=1024), configs[4]'s per-GPU share (ViPC, B=32, T=32), shipped T=32
+  rccl_ranks_seen  ranks that met in a one-int RCCL all-gather before the model was built (0: no launcher / single process)
 """
 import argparse
 import ctypes

@@ -1275,7 +1275,7 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
     const GemmArgs* a = &a_copy;
     LDT_REQUIRE(gemm256_takes(EPI, a), LDT_ESHAPE, "gemm256: M=%d N=%d must be multiples of 256, K=%d of 64 (>= 128), rows 16-byte aligned", a->M, a->N, a->K);
     // W from registers (kernel <.., .., 1, 1>: the one-tile-per-workgroup residual GEMMs): the caller's fragment-order copy
-    constexpr bool WREG_BUILT = (EPI == EPI_RESID_F32);
+    constexpr bool WREG_BUILT = (EPI == EPI_RESID_F32) && V3_PREISSUE == 1 && V3_SCHED == 0;   // (its counted waits assume the shipped request schedule: the tools/dbg schedule builds go without it)
     static const int wreg_env = getenv("LDT_GEMM_WREG") ? atoi(getenv("LDT_GEMM_WREG")) : -1;      // 0: off even when Wp is given; 1: pack on the fly (tools/dbg)
     const int wreg_dbg = g_dbg_wreg.load() >= 0 ? g_dbg_wreg.load() : wreg_env;
     const int tiles = tm * tn;
@@ -1292,8 +1292,13 @@ static int launch_256(const GemmArgs* a_in, hipStream_t stream) {
         LDT_ENSURE_LDS((&gemm_bf16_nt_256f_kernel<EPI, FOLD, 1, W, KL>), V2_LDS_BYTES, "gemm256f");                                \
         hipLaunchKernelGGL((gemm_bf16_nt_256f_kernel<EPI, FOLD, 1, W, KL>), dim3(grid), dim3(512), V2_LDS_BYTES, stream, *a);     \
     } while (0)
-            if (wreg) { if (klong) LAUNCH_XR(1, 1); else LAUNCH_XR(1, 0); }
-            else { if (klong) LAUNCH_XR(0, 1); else LAUNCH_XR(0, 0); }
+            if constexpr (WREG_BUILT) {
+                if (wreg) {
+                    if (klong) LAUNCH_XR(1, 1); else LAUNCH_XR(1, 0);
+                    return ldt_check_launch("gemm_bf16_nt_256f");
+                }
+            }
+            if (klong) LAUNCH_XR(0, 1); else LAUNCH_XR(0, 0);
 #undef LAUNCH_XR
             return ldt_check_launch("gemm_bf16_nt_256f");
         }
