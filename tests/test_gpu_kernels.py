@@ -590,14 +590,18 @@ torch.save(outs, sys.argv[1])
     res = {}
     # third child (round 6): the one-tile residual GEMMs with the weight operand loaded straight into registers from a fragment-order copy
     # (gemm_bf16.hip WREG: asm loads, hand-counted waits, no W in LDS; LDT_GEMM_WREG=1 packs the copy on the fly) — same MFMA order, same bits
-    for ring, wreg in (("0", "0"), ("1", "0"), ("1", "1")):
-        out = tmp_path / ("ring%s_wreg%s.pt" % (ring, wreg))
+    # fourth / fifth child (round 6): the grouped tile order of the multi-tile kernels (groups of 4 row panels by default; 8 until round 5, 1 =
+    # row-major) only permutes which workgroup computes which tile — every tile's arithmetic is the same
+    for ring, wreg, gm in (("0", "0", ""), ("1", "0", ""), ("1", "1", ""), ("1", "0", "8"), ("1", "0", "1")):
+        out = tmp_path / ("ring%s_wreg%s_gm%s.pt" % (ring, wreg, gm))
         env = dict(os.environ, LDT_RESID_RING=ring, LDT_GEMM_WREG=wreg)
+        if gm:
+            env["LDT_GEMM_GM"] = gm
         r = subprocess.run([sys.executable, "-c", child, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[(ring, wreg)] = torch.load(out)
-    base = res[("0", "0")]
+        res[(ring, wreg, gm)] = torch.load(out)
+    base = res[("0", "0", "")]
     for key, cur in res.items():
         for k in base:
-            assert torch.equal(cur[k], base[k]), "LDT_RESID_RING=%s LDT_GEMM_WREG=%s differs from the register-epilogue path in %s" % (key + (k,))
+            assert torch.equal(cur[k], base[k]), "LDT_RESID_RING=%s LDT_GEMM_WREG=%s LDT_GEMM_GM=%s differs from the register-epilogue path in %s" % (key + (k,))
     assert bool(torch.isfinite(base["x1"]).all()) and float(base["x1"].abs().mean()) > 0.1 and float(base["u"].float().abs().mean()) > 0.01
